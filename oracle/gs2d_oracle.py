@@ -1,0 +1,193 @@
+"""ctypes/numpy front-end of the CPU ORACLE (oracle/gs2d_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The shipped package (gaus_slam_amd/) never
+imports this module.  Parity status: "parity unpinned" against the reference
+binary (see the header of gs2d_oracle.c and DESIGN.md).
+
+The call structure mirrors the reference stage driver
+RAST/cuda_rasterizer/rasterizer_impl.cu:201-350 (forward) and :354-460
+(backward), and the tensor conventions of RAST/rasterize_points.cu:39-239.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgs2d_oracle.so")
+_lib = None
+
+TILE = 16
+
+
+def build(force=False):
+    """Compile the C oracle with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "gs2d_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libgs2d_oracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_preprocess.restype = C.c_int64
+        _lib.orc_higher_msb.restype = C.c_uint32
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "oracle arrays must be contiguous"
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def higher_msb(n):
+    return int(lib().orc_higher_msb(C.c_uint32(n)))
+
+
+def set_threads(n):
+    lib().orc_set_threads(C.c_int(int(n)))
+
+
+def forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy,
+            scales=None, rotations=None, colors_precomp=None, shs=None, sh_degree=0,
+            transMat_precomp=None, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, use_sa=True,
+            want_stability=True):
+    """Full forward.  Returns a dict with outputs and every intermediate.
+
+    viewmatrix / projmatrix: flat 16 floats, column-major (the transposed
+    matrices render/render_2dgs.py:10-24 builds)."""
+    L = lib()
+    means3D = _f32(means3D).reshape(-1, 3)
+    P = means3D.shape[0]
+    opacities = _f32(opacities).reshape(-1)
+    scales = _f32(scales)
+    rotations = _f32(rotations)
+    colors_precomp = _f32(colors_precomp)
+    transMat_precomp = _f32(transMat_precomp)
+    shs = _f32(shs)
+    M = 0 if shs is None else shs.shape[1]
+    vm = _f32(viewmatrix).reshape(16)
+    pm = _f32(projmatrix).reshape(16)
+    campos = _f32(campos).reshape(3)
+    bg = _f32(np.asarray(bg)).reshape(3)
+    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    HW = H * W
+    st = dict(P=P, W=W, H=H, M=M, D=sh_degree, use_sa=bool(use_sa), tanfovx=float(tanfovx),
+              tanfovy=float(tanfovy), scale_modifier=float(scale_modifier),
+              means3D=means3D, opacities=opacities, scales=scales, rotations=rotations,
+              colors_precomp=colors_precomp, transMat_precomp=transMat_precomp, shs=shs,
+              viewmatrix=vm, projmatrix=pm, campos=campos, bg=bg)
+    radii = np.zeros(P, np.int32)
+    means2D = np.zeros((P, 2), np.float32)
+    depths = np.zeros(P, np.float32)
+    transMats = np.zeros((P, 9), np.float32)
+    rgb = np.zeros((P, 3), np.float32)
+    normal_opacity = np.zeros((P, 4), np.float32)
+    tiles_touched = np.zeros(P, np.uint32)
+    clamped = np.zeros((P, 3), np.uint8)
+    point_offsets = np.zeros(P, np.uint32)
+    R = 0
+    if P > 0:
+        R = int(L.orc_preprocess(
+            C.c_int(P), C.c_int(sh_degree), C.c_int(M), _p(means3D), _p(scales),
+            C.c_float(scale_modifier), _p(rotations), _p(opacities), _p(shs), _p(transMat_precomp),
+            _p(colors_precomp), _p(vm), _p(pm), _p(campos), C.c_int(W), C.c_int(H),
+            _p(radii), _p(means2D), _p(depths), _p(transMats), _p(rgb), _p(normal_opacity),
+            _p(tiles_touched), _p(clamped), _p(point_offsets)))
+    keys_unsorted = np.zeros(R, np.uint64)
+    vals_unsorted = np.zeros(R, np.uint32)
+    keys = np.zeros(R, np.uint64)
+    point_list = np.zeros(R, np.uint32)
+    ranges = np.zeros((gx * gy, 2), np.uint32)
+    nbits = 32 + higher_msb(gx * gy)
+    if P > 0:
+        L.orc_duplicate(C.c_int(P), _p(means2D), _p(depths), _p(point_offsets), _p(radii),
+                        C.c_int(W), C.c_int(H), _p(keys_unsorted), _p(vals_unsorted))
+        L.orc_sort_pairs(C.c_int64(R), _p(keys_unsorted), _p(vals_unsorted), _p(keys), _p(point_list),
+                         C.c_int(nbits))
+        L.orc_tile_ranges(C.c_int64(R), _p(keys), C.c_int(gx * gy), _p(ranges))
+    out_color = np.zeros((3, H, W), np.float32)
+    out_others = np.zeros((7, H, W), np.float32)
+    final_T = np.zeros(3 * HW, np.float32)
+    n_contrib = np.zeros(2 * HW, np.uint32)
+    median_depth = np.zeros(HW, np.float32)
+    depth_std = np.zeros(HW, np.float32)
+    stab = np.full(HW, 1e30, np.float32) if want_stability else None
+    features = colors_precomp if colors_precomp is not None else rgb
+    tm = transMat_precomp if transMat_precomp is not None else transMats
+    if P > 0:
+        L.orc_blend_fwd(C.c_int(W), C.c_int(H), _p(ranges), _p(point_list), _p(means2D), _p(features),
+                        _p(tm), _p(normal_opacity), _p(bg), C.c_int(int(use_sa)),
+                        _p(out_color), _p(out_others), _p(final_T), _p(n_contrib),
+                        _p(median_depth), _p(depth_std), _p(stab))
+    st.update(num_rendered=R, radii=radii, means2D=means2D, depths=depths, transMats=transMats, rgb=rgb,
+              normal_opacity=normal_opacity, tiles_touched=tiles_touched, clamped=clamped,
+              point_offsets=point_offsets, keys_unsorted=keys_unsorted, vals_unsorted=vals_unsorted,
+              keys=keys, point_list=point_list, ranges=ranges, nbits=nbits,
+              color=out_color, allmap=out_others, final_T=final_T, n_contrib=n_contrib,
+              median_depth=median_depth, depth_std=depth_std, stability=stab)
+    return st
+
+
+def backward(st, dL_dcolor, dL_dallmap):
+    """Backward for a forward() state.  Returns the 8 gradients of
+    RAST/rasterize_points.cu:238 (+ the internal dL_dnormal)."""
+    L = lib()
+    P, W, H, M = st["P"], st["W"], st["H"], st["M"]
+    dL_dcolor = _f32(dL_dcolor).reshape(3, H, W)
+    dL_dallmap = _f32(dL_dallmap).reshape(7, H, W)
+    g = dict(
+        dL_dmeans3D=np.zeros((P, 3), np.float32), dL_dmeans2D=np.zeros((P, 3), np.float32),
+        dL_dcolors=np.zeros((P, 3), np.float32), dL_dnormal=np.zeros((P, 3), np.float32),
+        dL_dopacity=np.zeros((P, 1), np.float32), dL_dtransMat=np.zeros((P, 9), np.float32),
+        dL_dsh=np.zeros((P, M, 3), np.float32), dL_dscales=np.zeros((P, 2), np.float32),
+        dL_drotations=np.zeros((P, 4), np.float32))
+    if P == 0:
+        return g
+    features = st["colors_precomp"] if st["colors_precomp"] is not None else st["rgb"]
+    tm = st["transMat_precomp"] if st["transMat_precomp"] is not None else st["transMats"]
+    L.orc_blend_bwd(C.c_int(P), C.c_int(W), C.c_int(H), _p(st["ranges"]), _p(st["point_list"]),
+                    _p(st["bg"]), _p(st["means2D"]), _p(st["normal_opacity"]), _p(tm), _p(features),
+                    _p(st["final_T"]), _p(st["n_contrib"]), _p(dL_dcolor), _p(dL_dallmap),
+                    _p(st["median_depth"]), _p(st["depth_std"]), C.c_int(int(st["use_sa"])),
+                    _p(g["dL_dtransMat"]), _p(g["dL_dmeans2D"]), _p(g["dL_dnormal"]),
+                    _p(g["dL_dopacity"]), _p(g["dL_dcolors"]))
+    g["dL_dtransMat_blend"] = g["dL_dtransMat"].copy()
+    g["dL_dmeans2D_blend"] = g["dL_dmeans2D"].copy()
+    L.orc_preprocess_bwd(C.c_int(P), C.c_int(st["D"]), C.c_int(M), _p(st["means3D"]), _p(tm),
+                         _p(st["radii"]), _p(st["shs"]), _p(st["clamped"]), _p(st["scales"]),
+                         _p(st["rotations"]), C.c_float(st["scale_modifier"]), _p(st["viewmatrix"]),
+                         _p(st["projmatrix"]), C.c_int(W), C.c_int(H), C.c_float(st["tanfovx"]),
+                         C.c_float(st["tanfovy"]), _p(st["campos"]),
+                         _p(g["dL_dtransMat"]), _p(g["dL_dnormal"]), _p(g["dL_dcolors"]), _p(g["dL_dsh"]),
+                         _p(g["dL_dmeans2D"]), _p(g["dL_dmeans3D"]), _p(g["dL_dscales"]),
+                         _p(g["dL_drotations"]))
+    return g
+
+
+def mark_visible(means3D, viewmatrix):
+    means3D = _f32(means3D).reshape(-1, 3)
+    out = np.zeros(means3D.shape[0], np.uint8)
+    if means3D.shape[0]:
+        lib().orc_mark_visible(C.c_int(means3D.shape[0]), _p(means3D), _p(_f32(viewmatrix).reshape(16)), _p(out))
+    return out.astype(bool)
+
+
+def dist2_knn3(points):
+    """simple_knn.distCUDA2 semantics (mean squared distance to the 3 nearest other points)."""
+    pts = _f32(points).reshape(-1, 3)
+    out = np.zeros(pts.shape[0], np.float32)
+    if pts.shape[0]:
+        lib().orc_dist2_knn3(C.c_int(pts.shape[0]), _p(pts), _p(out))
+    return out
