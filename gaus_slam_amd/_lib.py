@@ -1,0 +1,53 @@
+"""ctypes binding of the C ABI (include/gs2d_rasterizer.h).  Fails loudly when the HIP library is missing:
+there is no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+EXPORTS = ["gs2d_forward", "gs2d_backward", "gs2d_mark_visible", "sknn_dist2", "gs2d_geometry_bytes",
+           "gs2d_image_bytes", "gs2d_binning_bytes", "gs2d_geometry_layout", "gs2d_binning_layout",
+           "gs2d_image_layout", "gs2d_last_error", "gs2d_build_info"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"gaus_slam_amd: HIP library {path} is missing. Build it with `python -m gaus_slam_amd.build` "
+            "(needs hipcc); this package has no CPU fallback.")
+    L = C.CDLL(path)
+    vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.gs2d_forward.restype = i
+    L.gs2d_forward.argtypes = [ALLOC_FN, vp, ALLOC_FN, vp, ALLOC_FN, vp, i, i, i, vp, i, i, vp, vp, vp, vp, vp, f, vp, vp,
+                               vp, vp, vp, f, f, i, vp, vp, vp, i, i, vp]
+    L.gs2d_backward.restype = i
+    L.gs2d_backward.argtypes = [i, i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f, vp, vp, vp, vp, vp, vp,
+                                vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
+    L.gs2d_mark_visible.restype = i
+    L.gs2d_mark_visible.argtypes = [i, vp, vp, vp, vp, vp]
+    L.sknn_dist2.restype = i
+    L.sknn_dist2.argtypes = [i, vp, vp, ALLOC_FN, vp, vp]
+    for n in ("gs2d_geometry_bytes", "gs2d_binning_bytes"):
+        getattr(L, n).restype = sz
+        getattr(L, n).argtypes = [i]
+    L.gs2d_image_bytes.restype = sz
+    L.gs2d_image_bytes.argtypes = [i, i]
+    L.gs2d_geometry_layout.argtypes = [i, C.POINTER(sz)]
+    L.gs2d_binning_layout.argtypes = [i, C.POINTER(sz)]
+    L.gs2d_image_layout.argtypes = [i, i, C.POINTER(sz)]
+    L.gs2d_last_error.restype = C.c_char_p
+    L.gs2d_build_info.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().gs2d_last_error().decode()

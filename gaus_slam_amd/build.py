@@ -1,0 +1,42 @@
+"""Builds the gfx950 shared library (C ABI in include/gs2d_rasterizer.h) with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only container as well as on the GPU box.
+The .so is written in-tree (gaus_slam_amd/lib/) so it travels with the source snapshot.
+"""
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libgs2d_hip.so")
+SOURCES = ["gs2d_preprocess.hip", "gs2d_binning.hip", "gs2d_blend.hip", "gs2d_api.hip", "sknn.hip"]
+# -ffp-contract=off: the per-Gaussian geometry (tile rectangles, depth keys) must be reproducible on the host.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "gs2d_rasterizer.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    cmd = [hipcc] + FLAGS + ["-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(LIB_PATH)

@@ -1,0 +1,231 @@
+// C ABI of the rasterizer (include/gs2d_rasterizer.h): stage drivers for forward / backward.
+// Replaces CudaRasterizer::Rasterizer::{forward,backward,markVisible}
+// (RAST/cuda_rasterizer/rasterizer_impl.cu:141-153,201-350,354-460 of the reference).
+#include "gs2d_common.h"
+#include "../../include/gs2d_rasterizer.h"
+
+#include <stdio.h>
+#include <string.h>
+#include <string>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* what, hipError_t e)
+{
+    char buf[512];
+    snprintf(buf, sizeof(buf), "gs2d: %s: %s", what, hipGetErrorString(e));
+    g_err = buf;
+    return -1;
+}
+int fail_msg(const char* what)
+{
+    g_err = std::string("gs2d: ") + what;
+    return -1;
+}
+
+#define GS2D_CHECK(expr, what)                        \
+    do {                                              \
+        hipError_t _e = (expr);                       \
+        if (_e != hipSuccess) return fail(what, _e);  \
+    } while (0)
+
+// After every stage when `debug` is set (the reference's CHECK_CUDA, auxiliary.h:295-302); launch errors always.
+#define GS2D_STAGE(what)                                                             \
+    do {                                                                             \
+        hipError_t _e = hipGetLastError();                                           \
+        if (_e != hipSuccess) return fail(what, _e);                                 \
+        if (debug) { _e = hipStreamSynchronize(s); if (_e != hipSuccess) return fail(what, _e); } \
+    } while (0)
+
+// rasterizer_impl.cu:35-50
+uint32_t higher_msb(uint32_t n)
+{
+    uint32_t msb = sizeof(n) * 4, step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step; else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+// pinned host word for the num_rendered read-back (one per host thread)
+struct PinnedWord {
+    uint32_t* p = nullptr;
+    ~PinnedWord() { if (p) (void)hipHostFree(p); }
+};
+thread_local PinnedWord g_pinned;
+
+}  // namespace
+
+extern "C" {
+
+const char* gs2d_last_error(void) { return g_err.c_str(); }
+
+const char* gs2d_build_info(void) { return "gs2d-hip gfx950 strict-fp (fp-contract=off) " __DATE__; }
+
+size_t gs2d_geometry_bytes(int P) { return geom_layout(P).total; }
+size_t gs2d_image_bytes(int width, int height) { return img_layout(width, height).total; }
+size_t gs2d_binning_bytes(int R) { return bin_layout(R).total; }
+
+void gs2d_geometry_layout(int P, size_t o[5])
+{
+    const GeomLayout L = geom_layout(P);
+    o[0] = L.depths; o[1] = L.tiles_touched; o[2] = L.point_offsets; o[3] = L.rec; o[4] = L.clamped;
+}
+void gs2d_binning_layout(int R, size_t o[2])
+{
+    const BinLayout L = bin_layout(R);
+    o[0] = L.point_list; o[1] = L.keys;
+}
+void gs2d_image_layout(int width, int height, size_t o[2])
+{
+    const ImgLayout L = img_layout(width, height);
+    o[0] = L.ranges; o[1] = L.pix;
+}
+
+int gs2d_forward(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_alloc_fn binning_alloc, void* binning_user,
+                 gs2d_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                 int height, const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                 const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                 float* out_others, int* radii, int use_sa, int debug, void* stream)
+{
+    (void)tan_fovx; (void)tan_fovy; (void)prefiltered;  // unused by the reference forward kernels as well (forward.cu:165)
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || width <= 0 || height <= 0) return fail_msg("bad sizes");
+    if (P == 0) return 0;  // rasterize_points.cu:100-101: zero images, rendered = 0 (outputs pre-zeroed by the caller)
+    if (!geometry_alloc || !binning_alloc || !image_alloc) return fail_msg("allocator callbacks are required");
+    if (colors_precomp == nullptr && shs == nullptr) return fail_msg("provide shs or colors_precomp");
+    if (transMat_precomp == nullptr && (scales == nullptr || rotations == nullptr))
+        return fail_msg("provide scales+rotations or transMat_precomp");
+    if (colors_precomp == nullptr && (M <= 0 || (D + 1) * (D + 1) > M)) return fail_msg("sh degree exceeds coefficients");
+
+    const GeomLayout GL = geom_layout(P);
+    char* geom = (char*)geometry_alloc(geometry_user, GL.total);
+    if (!geom) return fail_msg("geometry allocation failed");
+    const ImgLayout IL = img_layout(width, height);
+    char* img = (char*)image_alloc(image_user, IL.total);
+    if (!img) return fail_msg("image allocation failed");
+
+    CamParams cam;
+    cam.vm = viewmatrix; cam.pm = projmatrix; cam.campos = cam_pos;
+    cam.W = width; cam.H = height;
+    cam.gx = (width + GS2D_TILE - 1) / GS2D_TILE;
+    cam.gy = (height + GS2D_TILE - 1) / GS2D_TILE;
+
+    float* depths = (float*)(geom + GL.depths);
+    uint32_t* tiles_touched = (uint32_t*)(geom + GL.tiles_touched);
+    uint32_t* point_offsets = (uint32_t*)(geom + GL.point_offsets);
+    float4* rec = (float4*)(geom + GL.rec);
+    uint8_t* clamped = (uint8_t*)(geom + GL.clamped);
+    uint32_t* scan_tmp = (uint32_t*)(geom + GL.scan_tmp);
+
+    gs2d::launch_preprocess_fwd(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, transMat_precomp,
+                                colors_precomp, cam, radii, depths, rec, tiles_touched, clamped, s);
+    GS2D_STAGE("preprocess");
+
+    const int nblk = (P + GS2D_SCAN_ITEMS - 1) / GS2D_SCAN_ITEMS;
+    uint32_t* total_dev = scan_tmp + nblk + 8;
+    gs2d::launch_inclusive_scan(tiles_touched, point_offsets, P, scan_tmp, total_dev, s);
+    GS2D_STAGE("scan");
+
+    // The one host sync of the forward (rasterizer_impl.cu:287): the binning chunk is sized by num_rendered.
+    if (!g_pinned.p) GS2D_CHECK(hipHostMalloc((void**)&g_pinned.p, 64, hipHostMallocDefault), "hipHostMalloc");
+    GS2D_CHECK(hipMemcpyAsync(g_pinned.p, total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "memcpy num_rendered");
+    GS2D_CHECK(hipStreamSynchronize(s), "sync num_rendered");
+    const uint32_t num_rendered_u = *g_pinned.p;
+    if (num_rendered_u > 0x7fffffffu) return fail_msg("num_rendered overflows int32");
+    const int R = (int)num_rendered_u;
+
+    const BinLayout BL = bin_layout(R);
+    char* bin = (char*)binning_alloc(binning_user, BL.total);
+    if (!bin) return fail_msg("binning allocation failed");
+    uint32_t* point_list = (uint32_t*)(bin + BL.point_list);
+    uint64_t* keys = (uint64_t*)(bin + BL.keys);
+    uint32_t* vals_alt = (uint32_t*)(bin + BL.vals_alt);
+    uint64_t* keys_alt = (uint64_t*)(bin + BL.keys_alt);
+    uint32_t* hist = (uint32_t*)(bin + BL.hist);
+    uint2* ranges = (uint2*)(img + IL.ranges);
+    float* pix_state = (float*)(img + IL.pix);
+
+    const int end_bit = 32 + (int)higher_msb((uint32_t)(cam.gx * cam.gy));
+    const int passes = (end_bit + 7) / 8;
+    if (R > 0) {
+        // unsorted pairs go where the ping-pong needs them so that the result lands in (keys, point_list)
+        uint64_t* k_unsorted = (passes & 1) ? keys_alt : keys;
+        uint32_t* v_unsorted = (passes & 1) ? vals_alt : point_list;
+        gs2d::launch_duplicate(P, rec, depths, point_offsets, radii, cam.gx, cam.gy, k_unsorted, v_unsorted, s);
+        GS2D_STAGE("duplicate");
+        gs2d::launch_sort_pairs(R, keys, point_list, keys_alt, vals_alt, end_bit, hist, BL.hist_elems, s);
+        GS2D_STAGE("sort");
+    }
+    gs2d::launch_tile_ranges(R, keys, ranges, IL.tiles, s);
+    GS2D_STAGE("ranges");
+    gs2d::launch_blend_fwd(width, height, ranges, point_list, rec, background, out_color, out_others, pix_state,
+                           use_sa, s);
+    GS2D_STAGE("blend_fwd");
+    return R;
+}
+
+int gs2d_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                  const float* rotations, const float* transMat_precomp, const float* viewmatrix,
+                  const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                  char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix,
+                  const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor,
+                  float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot, int use_sa,
+                  int debug, void* stream)
+{
+    (void)colors_precomp; (void)transMat_precomp; (void)scale_modifier;
+    hipStream_t s = (hipStream_t)stream;
+    if (P <= 0) return 0;
+    if (!geom_buffer || !img_buffer || (R > 0 && !binning_buffer)) return fail_msg("missing forward state");
+    const GeomLayout GL = geom_layout(P);
+    const BinLayout BL = bin_layout(R);
+    const ImgLayout IL = img_layout(width, height);
+    const float4* rec = (const float4*)(geom_buffer + GL.rec);
+    const uint8_t* clamped = (const uint8_t*)(geom_buffer + GL.clamped);
+    float* grad_rec = (float*)(geom_buffer + GL.grad_rec);
+    const uint32_t* point_list = (const uint32_t*)(binning_buffer + BL.point_list);
+    const uint2* ranges = (const uint2*)(img_buffer + IL.ranges);
+    const float* pix_state = (const float*)(img_buffer + IL.pix);
+
+    GS2D_CHECK(hipMemsetAsync(grad_rec, 0, sizeof(float) * GS2D_GRAD_FLOATS * (size_t)P, s), "memset grad_rec");
+    if (R > 0) {
+        gs2d::launch_blend_bwd(width, height, ranges, point_list, rec, background, pix_state, dL_dpix, dL_depths,
+                               grad_rec, use_sa, s);
+        GS2D_STAGE("blend_bwd");
+    }
+    // rasterizer_impl.cu:396-397 + backward.cu:641-642: the backward rebuilds W,H from focal*tan in float32
+    const float focal_y = height / (2.0f * tan_fovy);
+    const float focal_x = width / (2.0f * tan_fovx);
+    CamParams cam;
+    cam.vm = viewmatrix; cam.pm = projmatrix; cam.campos = campos;
+    cam.W = (int)(focal_x * tan_fovx * 2);
+    cam.H = (int)(focal_y * tan_fovy * 2);
+    cam.gx = (width + GS2D_TILE - 1) / GS2D_TILE;
+    cam.gy = (height + GS2D_TILE - 1) / GS2D_TILE;
+    gs2d::launch_preprocess_bwd(P, D, M, means3D, rec, radii, shs, clamped, scales, rotations, cam, grad_rec,
+                                dL_dtransMat, dL_dnormal, dL_dcolor, dL_dopacity, dL_dsh, dL_dmean2D, dL_dmean3D,
+                                dL_dscale, dL_drot, s);
+    GS2D_STAGE("preprocess_bwd");
+    return 0;
+}
+
+int gs2d_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                      void* stream)
+{
+    (void)projmatrix;
+    hipStream_t s = (hipStream_t)stream;
+    const int debug = 0;
+    if (P <= 0) return 0;
+    gs2d::launch_mark_visible(P, means3D, viewmatrix, present, s);
+    GS2D_STAGE("mark_visible");
+    return 0;
+}
+
+}  // extern "C"

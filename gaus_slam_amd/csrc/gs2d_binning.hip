@@ -1,0 +1,283 @@
+// Tile binning: prefix sum of per-Gaussian tile counts, (tile|depth) key generation, stable LSD
+// radix sort of the 64-bit keys, per-tile ranges.
+//
+// Result contract (bit-exact with the reference pipeline): point_list ordered by
+// (tile id, float bits of view depth, Gaussian index) -- rasterizer_impl.cu:70-138,283-323 --
+// i.e. what cub::DeviceRadixSort::SortPairs (stable) yields on keys (tile << 32) | depth_bits whose
+// unsorted order is Gaussian-major.  The implementation is a hand-written wave64 radix sort:
+// 8-bit digits, per-workgroup digit histograms -> device scan -> stable scatter using ballot-based
+// match-any ranking (64-wide), no CUB/rocPRIM.
+#include "gs2d_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- device-wide inclusive scan (u32)
+// 3 kernels: per-block reduce, single-block scan of block sums, per-block scan + offset.
+constexpr int SCAN_T = 256;
+constexpr int SCAN_PER_T = GS2D_SCAN_ITEMS / SCAN_T;  // 4
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t n = __shfl_up(v, d, 64);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+
+// block-wide inclusive scan of one value per thread (256 threads); returns inclusive value, total in *total.
+__device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* total)
+{
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan(v, lane);
+    __syncthreads();  // protect wsum reuse across calls
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+        if (w < wave) base += wsum[w];
+    if (total) *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    return inc + base;
+}
+
+__global__ void __launch_bounds__(SCAN_T) scan_reduce_kernel(const uint32_t* __restrict__ in, int n, uint32_t* __restrict__ block_sums)
+{
+    const int base = blockIdx.x * GS2D_SCAN_ITEMS + threadIdx.x * SCAN_PER_T;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_T; i++)
+        if (base + i < n) s += in[base + i];
+    uint32_t total;
+    block_incl_scan(s, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// exclusive scan of block sums in place (single workgroup, loops over chunks); writes grand total.
+__global__ void __launch_bounds__(SCAN_T) scan_blocksums_kernel(uint32_t* __restrict__ block_sums, int nblocks, uint32_t* __restrict__ total_out)
+{
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int start = 0; start < nblocks; start += SCAN_T) {
+        const int i = start + threadIdx.x;
+        const uint32_t v = i < nblocks ? block_sums[i] : 0;
+        uint32_t total;
+        const uint32_t inc = block_incl_scan(v, &total);
+        const uint32_t carry = carry_s;
+        if (i < nblocks) block_sums[i] = carry + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry_s;
+}
+
+__global__ void __launch_bounds__(SCAN_T) scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n,
+                                                            const uint32_t* __restrict__ block_offsets)
+{
+    const int base = blockIdx.x * GS2D_SCAN_ITEMS + threadIdx.x * SCAN_PER_T;
+    uint32_t v[SCAN_PER_T];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_T; i++) {
+        v[i] = base + i < n ? in[base + i] : 0;
+        s += v[i];
+    }
+    const uint32_t inc = block_incl_scan(s, nullptr);
+    uint32_t run = block_offsets[blockIdx.x] + inc - s;
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_T; i++) {
+        run += v[i];
+        if (base + i < n) out[base + i] = run;
+    }
+}
+
+// ---------------------------------------------------------------- key generation
+__device__ __forceinline__ int f2i_sat(float v)
+{
+    if (!(v == v)) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (int)(-2147483647 - 1);
+    return (int)v;
+}
+
+// rasterizer_impl.cu:70-111; one thread per Gaussian, tiles emitted row-major (y outer, x inner).
+__global__ void __launch_bounds__(256)
+duplicate_kernel(int P, const float4* __restrict__ rec, const float* __restrict__ depths, const uint32_t* __restrict__ offsets,
+                 const int* __restrict__ radii, int gx, int gy, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const int rad = radii[idx];
+    if (rad <= 0) return;
+    uint32_t off = idx == 0 ? 0u : offsets[idx - 1];
+    const float px = rec[(size_t)idx * GS2D_REC_F4 + 0].w, py = rec[(size_t)idx * GS2D_REC_F4 + 1].w;
+    const float r = (float)rad;
+    const int minx = min(gx, max(0, f2i_sat((px - r) / (float)GS2D_TILE)));
+    const int miny = min(gy, max(0, f2i_sat((py - r) / (float)GS2D_TILE)));
+    const int maxx = min(gx, max(0, f2i_sat((px + r + (float)(GS2D_TILE - 1)) / (float)GS2D_TILE)));
+    const int maxy = min(gy, max(0, f2i_sat((py + r + (float)(GS2D_TILE - 1)) / (float)GS2D_TILE)));
+    const uint32_t dbits = __float_as_uint(depths[idx]);
+    for (int y = miny; y < maxy; y++)
+        for (int x = minx; x < maxx; x++) {
+            const uint64_t key = ((uint64_t)((uint32_t)y * (uint32_t)gx + (uint32_t)x) << 32) | dbits;
+            keys[off] = key;
+            vals[off] = (uint32_t)idx;
+            off++;
+        }
+}
+
+// ---------------------------------------------------------------- radix sort pass (8-bit digit)
+constexpr int SORT_T = 256;
+constexpr int SORT_PER_T = GS2D_SORT_ITEMS / SORT_T;  // 8 rounds of 64 per wave
+constexpr int WAVE_ITEMS = GS2D_SORT_ITEMS / 4;       // 512 consecutive elements per wave
+
+// element index handled by (wave, round, lane): consecutive within a wave-round, so that
+// (wave, round, lane) lexicographic order == element order (needed for stability).
+__device__ __forceinline__ int sort_elem(int block, int wave, int round, int lane)
+{
+    return block * GS2D_SORT_ITEMS + wave * WAVE_ITEMS + round * 64 + lane;
+}
+
+// hist[digit * nblocks + block] = number of keys of this block with that digit
+__global__ void __launch_bounds__(SORT_T)
+radix_hist_kernel(const uint64_t* __restrict__ keys, int n, int shift, uint32_t* __restrict__ hist, int nblocks)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < SORT_PER_T; r++) {
+        const int i = sort_elem(blockIdx.x, wave, r, lane);
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// `offs` = exclusive scan of hist (same indexing).  Stable scatter.
+__global__ void __launch_bounds__(SORT_T)
+radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
+                     uint32_t* __restrict__ vals_out, int n, int shift, const uint32_t* __restrict__ offs_incl, int nblocks)
+{
+    __shared__ uint32_t wcnt[4][256];  // per-wave running digit counts, later exclusive bases
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * 256; i += SORT_T) (&wcnt[0][0])[i] = 0;
+    __syncthreads();
+
+    uint64_t k[SORT_PER_T];
+    uint32_t rank[SORT_PER_T];  // rank among same-digit keys within this wave (stable)
+    const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < SORT_PER_T; r++) {
+        const int i = sort_elem(blockIdx.x, wave, r, lane);
+        const bool valid = i < n;
+        k[r] = valid ? keys_in[i] : 0;
+        const uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
+        // match-any over the 8 digit bits: peers = lanes holding the same digit (valid lanes only)
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint64_t vote = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? vote : ~vote;
+        }
+        const uint32_t before = wcnt[wave][d];  // same-wave LDS ops are ordered: read happens before the leader's write
+        rank[r] = before + (uint32_t)__popcll(peers & lt_mask);
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers & lt_mask) == 0) wcnt[wave][d] = before + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // turn per-wave totals into exclusive bases across waves and add the global offset of (digit, block)
+    {
+        const int d = threadIdx.x;
+        const size_t hidx = (size_t)d * nblocks + blockIdx.x;
+        // offs_incl is the INCLUSIVE scan of hist; exclusive start = inclusive - own count
+        const uint32_t c0 = wcnt[0][d], c1 = wcnt[1][d], c2 = wcnt[2][d], c3 = wcnt[3][d];
+        const uint32_t start = offs_incl[hidx] - (c0 + c1 + c2 + c3);
+        wcnt[0][d] = start;
+        wcnt[1][d] = start + c0;
+        wcnt[2][d] = start + c0 + c1;
+        wcnt[3][d] = start + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_PER_T; r++) {
+        const int i = sort_elem(blockIdx.x, wave, r, lane);
+        if (i < n) {
+            const uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
+            const uint32_t dst = wcnt[wave][d] + rank[r];
+            keys_out[dst] = k[r];
+            vals_out[dst] = vals_in[i];
+        }
+    }
+}
+
+// rasterizer_impl.cu:116-138
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= L) return;
+    const uint32_t cur = (uint32_t)(keys[idx] >> 32);
+    if (idx == 0) ranges[cur].x = 0;
+    else {
+        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
+        if (cur != prev) { ranges[prev].y = idx; ranges[cur].x = idx; }
+    }
+    if (idx == L - 1) ranges[cur].y = L;
+}
+
+}  // namespace
+
+namespace gs2d {
+
+void launch_inclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* tmp, uint32_t* total_out, hipStream_t s)
+{
+    if (n <= 0) return;
+    const int nblocks = (n + GS2D_SCAN_ITEMS - 1) / GS2D_SCAN_ITEMS;
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, in, n, tmp);
+    hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_T), 0, s, tmp, nblocks, total_out);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, in, out, n, tmp);
+}
+
+void launch_duplicate(int P, const float4* rec, const float* depths, const uint32_t* offsets, const int* radii,
+                      int gx, int gy, uint64_t* keys, uint32_t* vals, hipStream_t s)
+{
+    hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, rec, depths, offsets, radii, gx, gy,
+                       keys, vals);
+}
+
+void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int end_bit,
+                       uint32_t* hist, size_t hist_elems, hipStream_t s)
+{
+    if (R <= 0) return;
+    const int nblocks = (R + GS2D_SORT_ITEMS - 1) / GS2D_SORT_ITEMS;
+    uint32_t* scan_tmp = hist + hist_elems;
+    // data starts in the "b" buffers (unsorted) when the pass count is odd, so the result always lands in "a".
+    const int passes = (end_bit + 7) / 8;
+    uint64_t* kin = (passes & 1) ? keys_b : keys_a;
+    uint32_t* vin = (passes & 1) ? vals_b : vals_a;
+    uint64_t* kout = (passes & 1) ? keys_a : keys_b;
+    uint32_t* vout = (passes & 1) ? vals_a : vals_b;
+    for (int p = 0; p < passes; p++) {
+        const int shift = 8 * p;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(SORT_T), 0, s, kin, R, shift, hist, nblocks);
+        launch_inclusive_scan(hist, hist, (int)hist_elems, scan_tmp, nullptr, s);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(SORT_T), 0, s, kin, vin, kout, vout, R, shift, hist,
+                           nblocks);
+        uint64_t* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+    }
+}
+
+void launch_tile_ranges(int R, const uint64_t* keys, uint2* ranges, int tiles, hipStream_t s)
+{
+    (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)tiles, s);
+    if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, keys, ranges);
+}
+
+}  // namespace gs2d

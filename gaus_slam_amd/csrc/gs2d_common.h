@@ -1,0 +1,130 @@
+// Internal definitions shared by the gfx950 kernels of the 2D-Gaussian-surfel rasterizer.
+// Constants carried over verbatim from the reference (RAST/cuda_rasterizer/config.h:15-17,
+// auxiliary.h:37-59); everything else (memory layout, kernel decomposition) is this library's own.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define GS2D_TILE 16
+#define GS2D_TILE_PIX 256
+#define GS2D_NEAR_N 0.2f
+#define GS2D_FAR_N 100.0f
+#define GS2D_FILTER_INV_SQ 100.0f
+
+// Splat record: 5 x float4 = 80 B per Gaussian, written once by the forward preprocess and
+// gathered by both blend kernels (one record = everything a pixel needs about a splat):
+//   q0 = (Tu.x, Tu.y, Tu.z, center.x)   q1 = (Tv.x, Tv.y, Tv.z, center.y)
+//   q2 = (Tw.x, Tw.y, Tw.z, opacity)    q3 = (n.x, n.y, n.z, red)   q4 = (green, blue, 0, 0)
+#define GS2D_REC_F4 5
+#define GS2D_REC_FLOATS 20
+
+// Gradient record accumulated by the backward blend, consumed by the backward preprocess:
+//   [0..2] dL_dcolor  [3..5] dL_dnormal  [6..14] dL_dT (Tu,Tv,Tw)  [15,16] dL_dmean2D.xy  [17] dL_dopacity
+#define GS2D_GRAD_FLOATS 20
+
+// Pixel-state planes kept between forward and backward (element index = tile*256 + thread).
+enum { PS_TFINAL = 0, PS_M1, PS_M2, PS_MEDIAN, PS_STD, PS_LAST, PS_MEDC, PS_PLANES };
+
+static inline size_t gs2d_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct GeomLayout {
+    size_t depths, tiles_touched, point_offsets, rec, clamped, scan_tmp, grad_rec, total;
+};
+struct BinLayout {
+    size_t point_list, keys, vals_alt, keys_alt, hist, total;
+    size_t hist_elems;
+};
+struct ImgLayout {
+    size_t ranges, pix, total;
+    int tiles;
+};
+
+#define GS2D_SCAN_ITEMS 1024  // elements per workgroup in the device scan
+#define GS2D_SORT_ITEMS 2048  // elements per workgroup in one radix pass (256 threads x 8)
+
+static inline GeomLayout geom_layout(int P)
+{
+    GeomLayout L;
+    size_t o = 0;
+    const size_t p = (size_t)(P > 0 ? P : 1);
+    L.depths = o; o = gs2d_align_up(o + 4 * p, 256);
+    L.tiles_touched = o; o = gs2d_align_up(o + 4 * p, 256);
+    L.point_offsets = o; o = gs2d_align_up(o + 4 * p, 256);
+    L.rec = o; o = gs2d_align_up(o + 4 * GS2D_REC_FLOATS * p, 256);
+    L.clamped = o; o = gs2d_align_up(o + 3 * p, 256);
+    const size_t nblk = (p + GS2D_SCAN_ITEMS - 1) / GS2D_SCAN_ITEMS;
+    L.scan_tmp = o; o = gs2d_align_up(o + 4 * (nblk + 64), 256);
+    // backward-time accumulator (the reference backward has no allocator callback, so it is reserved here)
+    L.grad_rec = o; o = gs2d_align_up(o + 4 * GS2D_GRAD_FLOATS * p, 256);
+    L.total = o;
+    return L;
+}
+
+static inline BinLayout bin_layout(int R)
+{
+    BinLayout L;
+    size_t o = 0;
+    const size_t r = (size_t)(R > 0 ? R : 1);
+    L.point_list = o; o = gs2d_align_up(o + 4 * r, 256);
+    L.keys = o; o = gs2d_align_up(o + 8 * r, 256);
+    L.vals_alt = o; o = gs2d_align_up(o + 4 * r, 256);
+    L.keys_alt = o; o = gs2d_align_up(o + 8 * r, 256);
+    const size_t nblk = (r + GS2D_SORT_ITEMS - 1) / GS2D_SORT_ITEMS;
+    L.hist_elems = 256 * nblk;
+    const size_t scan_blk = (L.hist_elems + GS2D_SCAN_ITEMS - 1) / GS2D_SCAN_ITEMS;
+    L.hist = o; o = gs2d_align_up(o + 4 * (L.hist_elems + scan_blk + 64), 256);
+    L.total = o;
+    return L;
+}
+
+static inline ImgLayout img_layout(int W, int H)
+{
+    ImgLayout L;
+    const int gx = (W + GS2D_TILE - 1) / GS2D_TILE, gy = (H + GS2D_TILE - 1) / GS2D_TILE;
+    L.tiles = gx * gy;
+    size_t o = 0;
+    const size_t t = (size_t)(L.tiles > 0 ? L.tiles : 1);
+    L.ranges = o; o = gs2d_align_up(o + 8 * t, 256);
+    L.pix = o; o = gs2d_align_up(o + 4 * (size_t)PS_PLANES * t * GS2D_TILE_PIX, 256);
+    L.total = o;
+    return L;
+}
+
+// Camera constants passed by value to the per-Gaussian kernels.
+struct CamParams {
+    const float* vm;      // device, 16 floats column-major (wave-uniform scalar loads in the kernels)
+    const float* pm;      // device, 16 floats column-major
+    const float* campos;  // device, 3 floats
+    int W, H;      // forward: true size; backward: size rebuilt as the reference does (backward.cu:641-642)
+    int gx, gy;
+};
+
+// Internal launchers (defined in the .hip files).
+namespace gs2d {
+void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
+                           const float* rotations, const float* opacities, const float* shs,
+                           const float* transMat_precomp, const float* colors_precomp, const CamParams& cam,
+                           int* radii, float* depths, float4* rec, uint32_t* tiles_touched, uint8_t* clamped,
+                           hipStream_t s);
+void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float4* rec, const int* radii,
+                           const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
+                           const CamParams& cam, const float* grad_rec, float* dL_dtransMat, float* dL_dnormal,
+                           float* dL_dcolor, float* dL_dopacity, float* dL_dsh, float* dL_dmean2D,
+                           float* dL_dmean3D, float* dL_dscale, float* dL_drot, hipStream_t s);
+void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
+// inclusive scan of n u32; tmp must hold ceil(n/1024)+64 u32. If total_out != nullptr the grand total is stored there.
+void launch_inclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* tmp, uint32_t* total_out, hipStream_t s);
+void launch_duplicate(int P, const float4* rec, const float* depths, const uint32_t* offsets, const int* radii,
+                      int gx, int gy, uint64_t* keys, uint32_t* vals, hipStream_t s);
+// stable LSD radix sort of (u64 key, u32 val) pairs on key bits [0, end_bit). Result lands in keys_a/vals_a.
+void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int end_bit,
+                       uint32_t* hist, size_t hist_elems, hipStream_t s);
+void launch_tile_ranges(int R, const uint64_t* keys, uint2* ranges, int tiles, hipStream_t s);
+void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
+                      const float* bg, float* out_color, float* out_others, float* pix_state, int use_sa,
+                      hipStream_t s);
+void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
+                      const float* bg, const float* pix_state, const float* dL_dpix, const float* dL_dothers,
+                      float* grad_rec, int use_sa, hipStream_t s);
+}  // namespace gs2d

@@ -1,0 +1,434 @@
+// Per-Gaussian kernels: forward preprocess (projection, bounding, colour), backward preprocess
+// (dL/dT -> means/scales/rotations, SH backward), frustum marking.
+//
+// Semantics follow RAST/cuda_rasterizer/forward.cu:20-253, backward.cu:20-139,466-664 and
+// auxiliary.h:61-291 of the reference; the code is written for gfx950 with plain float math
+// (no glm), one thread per Gaussian, SoA inputs read coalesced, one packed 80-byte record out.
+//
+// This file MUST be compiled with -ffp-contract=off: tile rectangles, radii and depth keys are
+// compared bit-exactly with the CPU oracle, and the expression order below is part of that contract.
+#include "gs2d_common.h"
+
+namespace {
+
+__constant__ float SH_C0 = 0.28209479177387814f;
+__constant__ float SH_C1 = 0.4886025119029199f;
+__constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                               -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                               0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                               -0.5900435899266435f};
+
+// float -> int32: truncation toward zero, saturating, NaN -> 0 (what v_cvt_i32_f32 does, spelled out
+// so the optimiser cannot treat out-of-range inputs as poison).
+__device__ __forceinline__ int f2i_sat(float v)
+{
+    if (!(v == v)) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (int)(-2147483647 - 1);
+    return (int)v;
+}
+
+// auxiliary.h:66-76
+__device__ __forceinline__ void get_rect(float px, float py, int max_radius, int gx, int gy, int& minx, int& miny,
+                                         int& maxx, int& maxy)
+{
+    const float r = (float)max_radius;
+    minx = min(gx, max(0, f2i_sat((px - r) / (float)GS2D_TILE)));
+    miny = min(gy, max(0, f2i_sat((py - r) / (float)GS2D_TILE)));
+    maxx = min(gx, max(0, f2i_sat((px + r + (float)(GS2D_TILE - 1)) / (float)GS2D_TILE)));
+    maxy = min(gy, max(0, f2i_sat((py + r + (float)(GS2D_TILE - 1)) / (float)GS2D_TILE)));
+}
+
+struct Mat3 {
+    float m[3][3];  // m[row][col]
+};
+
+// auxiliary.h:212-234; IEEE 1/sqrt instead of the approximate rsqrt so the result is reproducible on the host.
+__device__ __forceinline__ Mat3 quat_to_R(const float4 q /* w,x,y,z */, float& w, float& x, float& y, float& z)
+{
+    const float s = 1.0f / sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    w = q.x * s; x = q.y * s; y = q.z * s; z = q.w * s;
+    Mat3 R;
+    R.m[0][0] = 1.f - 2.f * (y * y + z * z);
+    R.m[1][0] = 2.f * (x * y + w * z);
+    R.m[2][0] = 2.f * (x * z - w * y);
+    R.m[0][1] = 2.f * (x * y - w * z);
+    R.m[1][1] = 1.f - 2.f * (x * x + z * z);
+    R.m[2][1] = 2.f * (y * z + w * x);
+    R.m[0][2] = 2.f * (x * z + w * y);
+    R.m[1][2] = 2.f * (y * z - w * x);
+    R.m[2][2] = 1.f - 2.f * (x * x + y * y);
+    return R;
+}
+
+// forward.cu:75-115 / backward.cu:503-528.  T rows: Tu (T[0..2]), Tv (T[3..5]), Tw (T[6..8]).
+__device__ __forceinline__ void compute_transmat(const float px, const float py, const float pz, const float sx,
+                                                 const float sy, const Mat3& R, const float* pm, const float* vm,
+                                                 int W, int H, float T[9], float normal[3])
+{
+    const float halfW = (float)W * 0.5f, halfWm = (float)(W - 1) * 0.5f;
+    const float halfH = (float)H * 0.5f, halfHm = (float)(H - 1) * 0.5f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float hx, hy, hz;
+        if (i == 0) { hx = R.m[0][0] * sx; hy = R.m[1][0] * sx; hz = R.m[2][0] * sx; }
+        else if (i == 1) { hx = R.m[0][1] * sy; hy = R.m[1][1] * sy; hz = R.m[2][1] * sy; }
+        else { hx = px; hy = py; hz = pz; }
+        float q0 = (pm[0] * hx + pm[4] * hy) + pm[8] * hz;
+        float q1 = (pm[1] * hx + pm[5] * hy) + pm[9] * hz;
+        float q3 = (pm[3] * hx + pm[7] * hy) + pm[11] * hz;
+        if (i == 2) { q0 = q0 + pm[12]; q1 = q1 + pm[13]; q3 = q3 + pm[15]; }
+        T[0 + i] = q0 * halfW + q3 * halfWm;
+        T[3 + i] = q1 * halfH + q3 * halfHm;
+        T[6 + i] = q3;
+    }
+    const float lx = R.m[0][2], ly = R.m[1][2], lz = R.m[2][2];
+    normal[0] = (vm[0] * lx + vm[4] * ly) + vm[8] * lz;
+    normal[1] = (vm[1] * lx + vm[5] * ly) + vm[9] * lz;
+    normal[2] = (vm[2] * lx + vm[6] * ly) + vm[10] * lz;
+}
+
+// forward.cu:20-71
+__device__ void sh_to_rgb(int idx, int deg, int M, const float* means, const float* campos, const float* shs,
+                          uint8_t* clamped, float out[3])
+{
+    const float dx = means[3 * idx] - campos[0], dy = means[3 * idx + 1] - campos[1], dz = means[3 * idx + 2] - campos[2];
+    const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float x = dx / len, y = dy / len, z = dz / len;
+    const float* sh = shs + (size_t)idx * M * 3;
+    for (int c = 0; c < 3; c++) {
+#define SHC(k) sh[(k) * 3 + c]
+        float r = SH_C0 * SHC(0);
+        if (deg > 0) {
+            r = r - SH_C1 * y * SHC(1) + SH_C1 * z * SHC(2) - SH_C1 * x * SHC(3);
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                r = r + SH_C2[0] * xy * SHC(4) + SH_C2[1] * yz * SHC(5) + SH_C2[2] * (2.0f * zz - xx - yy) * SHC(6) +
+                    SH_C2[3] * xz * SHC(7) + SH_C2[4] * (xx - yy) * SHC(8);
+                if (deg > 2) {
+                    r = r + SH_C3[0] * y * (3.0f * xx - yy) * SHC(9) + SH_C3[1] * xy * z * SHC(10) +
+                        SH_C3[2] * y * (4.0f * zz - xx - yy) * SHC(11) +
+                        SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SHC(12) +
+                        SH_C3[4] * x * (4.0f * zz - xx - yy) * SHC(13) + SH_C3[5] * z * (xx - yy) * SHC(14) +
+                        SH_C3[6] * x * (xx - 3.0f * yy) * SHC(15);
+                }
+            }
+        }
+#undef SHC
+        r += 0.5f;
+        clamped[3 * idx + c] = (r < 0);
+        out[c] = fmaxf(r, 0.0f);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
+                      float scale_modifier, const float* __restrict__ rotations, const float* __restrict__ opacities,
+                      const float* __restrict__ shs, const float* __restrict__ transMat_precomp,
+                      const float* __restrict__ colors_precomp, const CamParams cam, int* __restrict__ radii,
+                      float* __restrict__ depths, float4* __restrict__ rec, uint32_t* __restrict__ tiles_touched,
+                      uint8_t* __restrict__ clamped)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    // forward.cu:183-184: invisible unless proven otherwise
+    int out_radius = 0;
+    uint32_t out_tiles = 0;
+    float out_depth = 0.f;
+    float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0, r4 = r0;
+
+    const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+    const float* vm = cam.vm;
+    const float pvx = ((vm[0] * px + vm[4] * py) + vm[8] * pz) + vm[12];
+    const float pvy = ((vm[1] * px + vm[5] * py) + vm[9] * pz) + vm[13];
+    const float pvz = ((vm[2] * px + vm[6] * py) + vm[10] * pz) + vm[14];
+    do {
+        if (pvz <= 0.2f) break;  // auxiliary.h:199
+        float T[9], normal[3];
+        if (transMat_precomp == nullptr) {
+            const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+            const float2 sc = reinterpret_cast<const float2*>(scales)[idx];
+            float w, x, y, z;
+            const Mat3 R = quat_to_R(q, w, x, y, z);
+            compute_transmat(px, py, pz, scale_modifier * sc.x, scale_modifier * sc.y, R, cam.pm, cam.vm, cam.W,
+                             cam.H, T, normal);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; i++) T[i] = transMat_precomp[9 * (size_t)idx + i];
+            normal[0] = 0.f; normal[1] = 0.f; normal[2] = 1.f;
+        }
+        // forward.cu:211-216
+        const float cosv = -((pvx * normal[0] + pvy * normal[1]) + pvz * normal[2]);
+        if (cosv == 0) break;
+        const float mult = cosv > 0 ? 1.f : -1.f;
+        normal[0] = mult * normal[0]; normal[1] = mult * normal[1]; normal[2] = mult * normal[2];
+        // forward.cu:119-147, cutoff 3
+        const float c2 = 3.0f * 3.0f;
+        const float dist = ((T[6] * T[6]) * c2 + (T[7] * T[7]) * c2) + (T[8] * T[8]) * -1.0f;
+        const float inv = 1 / dist;
+        const float f0 = inv * c2, f1 = inv * c2, f2 = inv * -1.0f;
+        if (dist == 0.0f) break;
+        const float cx = ((f0 * T[0]) * T[6] + (f1 * T[1]) * T[7]) + (f2 * T[2]) * T[8];
+        const float cy = ((f0 * T[3]) * T[6] + (f1 * T[4]) * T[7]) + (f2 * T[5]) * T[8];
+        const float tx = ((f0 * T[0]) * T[0] + (f1 * T[1]) * T[1]) + (f2 * T[2]) * T[2];
+        const float ty = ((f0 * T[3]) * T[3] + (f1 * T[4]) * T[4]) + (f2 * T[5]) * T[5];
+        const float ex = sqrtf(fmaxf(1e-4f, cx * cx - tx));
+        const float ey = sqrtf(fmaxf(1e-4f, cy * cy - ty));
+        const float radius = ceilf(fmaxf(ex, ey));
+        int minx, miny, maxx, maxy;
+        get_rect(cx, cy, f2i_sat(radius), cam.gx, cam.gy, minx, miny, maxx, maxy);
+        if ((maxx - minx) * (maxy - miny) == 0) break;
+        float col[3];
+        if (colors_precomp == nullptr) sh_to_rgb(idx, D, M, means3D, cam.campos, shs, clamped, col);
+        else { col[0] = colors_precomp[3 * idx]; col[1] = colors_precomp[3 * idx + 1]; col[2] = colors_precomp[3 * idx + 2]; }
+        out_depth = pvz;
+        out_radius = f2i_sat(radius);
+        out_tiles = (uint32_t)((maxy - miny) * (maxx - minx));
+        r0 = make_float4(T[0], T[1], T[2], cx);
+        r1 = make_float4(T[3], T[4], T[5], cy);
+        r2 = make_float4(T[6], T[7], T[8], opacities[idx]);
+        r3 = make_float4(normal[0], normal[1], normal[2], col[0]);
+        r4 = make_float4(col[1], col[2], 0.f, 0.f);
+    } while (0);
+    radii[idx] = out_radius;
+    tiles_touched[idx] = out_tiles;
+    depths[idx] = out_depth;
+    float4* rp = rec + (size_t)idx * GS2D_REC_F4;
+    rp[0] = r0; rp[1] = r1; rp[2] = r2; rp[3] = r3; rp[4] = r4;
+}
+
+// backward.cu:20-139
+__device__ void sh_backward(int idx, int deg, int M, const float* means, const float* campos, const float* shs,
+                            const uint8_t* clamped, const float dL_dcolor[3], float dL_dmean[3], float* dL_dshs)
+{
+    const float ox = means[3 * idx] - campos[0], oy = means[3 * idx + 1] - campos[1], oz = means[3 * idx + 2] - campos[2];
+    const float len = sqrtf((ox * ox + oy * oy) + oz * oz);
+    const float x = ox / len, y = oy / len, z = oz / len;
+    const float* sh = shs + (size_t)idx * M * 3;
+    float* dsh = dL_dshs + (size_t)idx * M * 3;
+    float dRGB[3];
+    for (int c = 0; c < 3; c++) dRGB[c] = dL_dcolor[c] * (clamped[3 * idx + c] ? 0.f : 1.f);
+    float ddir[3] = {0, 0, 0};
+    for (int c = 0; c < 3; c++) {
+#define SHC(k) sh[(k) * 3 + c]
+#define DSH(k) dsh[(k) * 3 + c]
+        float dx = 0, dy = 0, dz = 0;
+        DSH(0) = SH_C0 * dRGB[c];
+        if (deg > 0) {
+            DSH(1) = (-SH_C1 * y) * dRGB[c];
+            DSH(2) = (SH_C1 * z) * dRGB[c];
+            DSH(3) = (-SH_C1 * x) * dRGB[c];
+            dx = -SH_C1 * SHC(3); dy = -SH_C1 * SHC(1); dz = SH_C1 * SHC(2);
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                DSH(4) = (SH_C2[0] * xy) * dRGB[c];
+                DSH(5) = (SH_C2[1] * yz) * dRGB[c];
+                DSH(6) = (SH_C2[2] * (2.f * zz - xx - yy)) * dRGB[c];
+                DSH(7) = (SH_C2[3] * xz) * dRGB[c];
+                DSH(8) = (SH_C2[4] * (xx - yy)) * dRGB[c];
+                dx += SH_C2[0] * y * SHC(4) + SH_C2[2] * 2.f * -x * SHC(6) + SH_C2[3] * z * SHC(7) + SH_C2[4] * 2.f * x * SHC(8);
+                dy += SH_C2[0] * x * SHC(4) + SH_C2[1] * z * SHC(5) + SH_C2[2] * 2.f * -y * SHC(6) + SH_C2[4] * 2.f * -y * SHC(8);
+                dz += SH_C2[1] * y * SHC(5) + SH_C2[2] * 2.f * 2.f * z * SHC(6) + SH_C2[3] * x * SHC(7);
+                if (deg > 2) {
+                    DSH(9) = (SH_C3[0] * y * (3.f * xx - yy)) * dRGB[c];
+                    DSH(10) = (SH_C3[1] * xy * z) * dRGB[c];
+                    DSH(11) = (SH_C3[2] * y * (4.f * zz - xx - yy)) * dRGB[c];
+                    DSH(12) = (SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * dRGB[c];
+                    DSH(13) = (SH_C3[4] * x * (4.f * zz - xx - yy)) * dRGB[c];
+                    DSH(14) = (SH_C3[5] * z * (xx - yy)) * dRGB[c];
+                    DSH(15) = (SH_C3[6] * x * (xx - 3.f * yy)) * dRGB[c];
+                    dx += (SH_C3[0] * SHC(9) * 3.f * 2.f * xy + SH_C3[1] * SHC(10) * yz + SH_C3[2] * SHC(11) * -2.f * xy +
+                           SH_C3[3] * SHC(12) * -3.f * 2.f * xz + SH_C3[4] * SHC(13) * (-3.f * xx + 4.f * zz - yy) +
+                           SH_C3[5] * SHC(14) * 2.f * xz + SH_C3[6] * SHC(15) * 3.f * (xx - yy));
+                    dy += (SH_C3[0] * SHC(9) * 3.f * (xx - yy) + SH_C3[1] * SHC(10) * xz +
+                           SH_C3[2] * SHC(11) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * SHC(12) * -3.f * 2.f * yz +
+                           SH_C3[4] * SHC(13) * -2.f * xy + SH_C3[5] * SHC(14) * -2.f * yz +
+                           SH_C3[6] * SHC(15) * -3.f * 2.f * xy);
+                    dz += (SH_C3[1] * SHC(10) * xy + SH_C3[2] * SHC(11) * 4.f * 2.f * yz +
+                           SH_C3[3] * SHC(12) * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * SHC(13) * 4.f * 2.f * xz +
+                           SH_C3[5] * SHC(14) * (xx - yy));
+                }
+            }
+        }
+#undef SHC
+#undef DSH
+        ddir[0] += dx * dRGB[c]; ddir[1] += dy * dRGB[c]; ddir[2] += dz * dRGB[c];
+    }
+    // auxiliary.h:127-137
+    const float sum2 = ox * ox + oy * oy + oz * oz;
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    dL_dmean[0] += ((+sum2 - ox * ox) * ddir[0] - oy * ox * ddir[1] - oz * ox * ddir[2]) * invsum32;
+    dL_dmean[1] += (-ox * oy * ddir[0] + (sum2 - oy * oy) * ddir[1] - oz * oy * ddir[2]) * invsum32;
+    dL_dmean[2] += (-ox * oz * ddir[0] - oy * oz * ddir[1] + (sum2 - oz * oz) * ddir[2]) * invsum32;
+}
+
+// backward.cu:466-664.  Reads the packed gradient record written by the backward blend, writes the
+// public gradient tensors (all pre-zeroed by the caller, so culled Gaussians stay zero).
+__global__ void __launch_bounds__(256)
+preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float4* __restrict__ rec,
+                      const int* __restrict__ radii, const float* __restrict__ shs,
+                      const uint8_t* __restrict__ clamped, const float* __restrict__ scales,
+                      const float* __restrict__ rotations, const CamParams cam, const float* __restrict__ grad_rec,
+                      float* __restrict__ dL_dtransMat, float* __restrict__ dL_dnormal, float* __restrict__ dL_dcolor,
+                      float* __restrict__ dL_dopacity, float* __restrict__ dL_dsh, float* __restrict__ dL_dmean2D,
+                      float* __restrict__ dL_dmean3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P || !(radii[idx] > 0)) return;
+    const float4* gr4 = reinterpret_cast<const float4*>(grad_rec) + (size_t)idx * (GS2D_GRAD_FLOATS / 4);
+    float g[GS2D_GRAD_FLOATS];
+#pragma unroll
+    for (int i = 0; i < GS2D_GRAD_FLOATS / 4; i++) {
+        const float4 v = gr4[i];
+        g[4 * i] = v.x; g[4 * i + 1] = v.y; g[4 * i + 2] = v.z; g[4 * i + 3] = v.w;
+    }
+    // unpack the blend-stage gradients into the public tensors
+    float dcol[3] = {g[0], g[1], g[2]};
+    dL_dcolor[3 * idx] = dcol[0]; dL_dcolor[3 * idx + 1] = dcol[1]; dL_dcolor[3 * idx + 2] = dcol[2];
+    dL_dnormal[3 * idx] = g[3]; dL_dnormal[3 * idx + 1] = g[4]; dL_dnormal[3 * idx + 2] = g[5];
+    dL_dopacity[idx] = g[17];
+    float dT[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) dT[i] = g[6 + i];
+    float dTout[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) dTout[i] = dT[i];  // what the reference leaves in dL_dtransMat
+    const float dmx = g[15], dmy = g[16];
+
+    const bool precomp = (scales == nullptr);
+    const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+    const float* pm = cam.pm;
+    const float* vm = cam.vm;
+    float T[9], normal[3] = {0.f, 0.f, 0.f};
+    float Pm[4][3];
+    Mat3 R;
+    float sx = 0.f, sy = 0.f, w = 0.f, x = 0.f, y = 0.f, z = 0.f;
+    const float4* rp = rec + (size_t)idx * GS2D_REC_F4;
+    const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+    if (precomp) {
+        T[0] = q0.x; T[1] = q0.y; T[2] = q0.z; T[3] = q1.x; T[4] = q1.y; T[5] = q1.z; T[6] = q2.x; T[7] = q2.y; T[8] = q2.z;
+    } else {
+        const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+        const float2 sc = reinterpret_cast<const float2*>(scales)[idx];
+        sx = sc.x; sy = sc.y;  // backward.cu:504: scale_modifier is ignored here
+        R = quat_to_R(q, w, x, y, z);
+        compute_transmat(px, py, pz, sx, sy, R, pm, vm, cam.W, cam.H, T, normal);
+        const float halfW = (float)cam.W * 0.5f, halfWm = (float)(cam.W - 1) * 0.5f;
+        const float halfH = (float)cam.H * 0.5f, halfHm = (float)(cam.H - 1) * 0.5f;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            Pm[a][0] = pm[4 * a] * halfW + pm[4 * a + 3] * halfWm;
+            Pm[a][1] = pm[4 * a + 1] * halfH + pm[4 * a + 3] * halfHm;
+            Pm[a][2] = pm[4 * a + 3];
+        }
+    }
+    bool early = false;
+    if (dmx != 0 || dmy != 0) {  // backward.cu:538-577
+        const float distance = T[6] * T[6] + T[7] * T[7] - T[8] * T[8];
+        const float f = 1 / distance;
+        dT[0] += dmx * (f * T[6]);
+        dT[1] += dmx * (f * T[7]);
+        dT[2] += dmx * (-f * T[8]);
+        dT[3] += dmy * (f * T[6]);
+        dT[4] += dmy * (f * T[7]);
+        dT[5] += dmy * (-f * T[8]);
+        dT[6] += dmx * (T[0] * (f - 2 * f * f * T[6] * T[6])) + dmy * (T[3] * (f - 2 * f * f * T[6] * T[6]));
+        dT[7] += dmx * (T[1] * (f - 2 * f * f * T[7] * T[7])) + dmy * (T[4] * (f - 2 * f * f * T[7] * T[7]));
+        dT[8] += dmx * (-T[2] * (f + 2 * f * f * T[8] * T[8])) + dmy * (-T[5] * (f + 2 * f * f * T[8] * T[8]));
+        if (precomp) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) dTout[i] = dT[i];
+            early = true;
+        }
+    }
+    float dmean[3] = {0.f, 0.f, 0.f};
+    bool have_mean = false;
+    if (!precomp && !early) {
+        float dh[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) dh[i][a] = (Pm[a][0] * dT[i] + Pm[a][1] * dT[3 + i]) + Pm[a][2] * dT[6 + i];
+        float dtn[3] = {(vm[0] * g[3] + vm[1] * g[4]) + vm[2] * g[5], (vm[4] * g[3] + vm[5] * g[4]) + vm[6] * g[5],
+                        (vm[8] * g[3] + vm[9] * g[4]) + vm[10] * g[5]};
+        const float pvx = ((vm[0] * px + vm[4] * py) + vm[8] * pz) + vm[12];
+        const float pvy = ((vm[1] * px + vm[5] * py) + vm[9] * pz) + vm[13];
+        const float pvz = ((vm[2] * px + vm[6] * py) + vm[10] * pz) + vm[14];
+        const float cosv = -((pvx * normal[0] + pvy * normal[1]) + pvz * normal[2]);
+        const float mult = cosv > 0 ? 1.f : -1.f;
+#pragma unroll
+        for (int a = 0; a < 3; a++) dtn[a] = mult * dtn[a];
+        float v[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) { v[r][0] = dh[0][r] * sx; v[r][1] = dh[1][r] * sy; v[r][2] = dtn[r]; }
+        // auxiliary.h:237-281
+        float4 dq;
+        dq.x = 2.f * (x * (v[2][1] - v[1][2]) + y * (v[0][2] - v[2][0]) + z * (v[1][0] - v[0][1]));
+        dq.y = 2.f * (-2.f * x * (v[1][1] + v[2][2]) + y * (v[1][0] + v[0][1]) + z * (v[2][0] + v[0][2]) + w * (v[2][1] - v[1][2]));
+        dq.z = 2.f * (x * (v[1][0] + v[0][1]) - 2.f * y * (v[0][0] + v[2][2]) + z * (v[2][1] + v[1][2]) + w * (v[0][2] - v[2][0]));
+        dq.w = 2.f * (x * (v[2][0] + v[0][2]) + y * (v[2][1] + v[1][2]) - 2.f * z * (v[0][0] + v[1][1]) + w * (v[1][0] - v[0][1]));
+        reinterpret_cast<float4*>(dL_drot)[idx] = dq;
+        float2 ds;
+        ds.x = (dh[0][0] * R.m[0][0] + dh[0][1] * R.m[1][0]) + dh[0][2] * R.m[2][0];
+        ds.y = (dh[1][0] * R.m[0][1] + dh[1][1] * R.m[1][1]) + dh[1][2] * R.m[2][1];
+        reinterpret_cast<float2*>(dL_dscale)[idx] = ds;
+        dmean[0] = dh[2][0]; dmean[1] = dh[2][1]; dmean[2] = dh[2][2];
+        have_mean = true;
+    }
+    if (shs != nullptr) {
+        sh_backward(idx, D, M, means3D, cam.campos, shs, clamped, dcol, dmean, dL_dsh);
+        have_mean = true;
+    }
+    if (have_mean) { dL_dmean3D[3 * idx] = dmean[0]; dL_dmean3D[3 * idx + 1] = dmean[1]; dL_dmean3D[3 * idx + 2] = dmean[2]; }
+#pragma unroll
+    for (int i = 0; i < 9; i++) dL_dtransMat[9 * (size_t)idx + i] = dTout[i];
+    // densification hack, backward.cu:660-663 (double arithmetic as written in the reference)
+    const float depth = q2.z;
+    dL_dmean2D[3 * idx + 0] = (float)((double)(dTout[2] * depth) * 0.5 * (double)(float)cam.W);
+    dL_dmean2D[3 * idx + 1] = (float)((double)(dTout[5] * depth) * 0.5 * (double)(float)cam.H);
+}
+
+// rasterizer_impl.cu:54-66
+__global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ vm,
+                                    uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+    const float pvz = ((vm[2] * px + vm[6] * py) + vm[10] * pz) + vm[14];
+    present[idx] = pvz > 0.2f;
+}
+
+}  // namespace
+
+namespace gs2d {
+
+void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
+                           const float* rotations, const float* opacities, const float* shs,
+                           const float* transMat_precomp, const float* colors_precomp, const CamParams& cam,
+                           int* radii, float* depths, float4* rec, uint32_t* tiles_touched, uint8_t* clamped,
+                           hipStream_t s)
+{
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales,
+                       scale_modifier, rotations, opacities, shs, transMat_precomp, colors_precomp, cam, radii, depths,
+                       rec, tiles_touched, clamped);
+}
+
+void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float4* rec, const int* radii,
+                           const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
+                           const CamParams& cam, const float* grad_rec, float* dL_dtransMat, float* dL_dnormal,
+                           float* dL_dcolor, float* dL_dopacity, float* dL_dsh, float* dL_dmean2D,
+                           float* dL_dmean3D, float* dL_dscale, float* dL_drot, hipStream_t s)
+{
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, rec, radii, shs,
+                       clamped, scales, rotations, cam, grad_rec, dL_dtransMat, dL_dnormal, dL_dcolor, dL_dopacity,
+                       dL_dsh, dL_dmean2D, dL_dmean3D, dL_dscale, dL_drot);
+}
+
+void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s)
+{
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, vm, present);
+}
+
+}  // namespace gs2d

@@ -1,0 +1,228 @@
+"""Host-side mirror of the reference operator surface for the 2D-Gaussian-surfel rasterizer.
+
+Same names, argument order, return order and error behaviour as
+RAST/gaus_2dgs_rasterization/__init__.py (GaussianRasterizationSettings :163-176, GaussianRasterizer :178-227,
+_RasterizeGaussians :44-161) and the pybind functions of RAST/ext.cpp:15-19 / RAST/rasterize_points.cu:39-260
+(rasterize_gaussians, rasterize_gaussians_backward, mark_visible), so render/render_2dgs.py and everything above
+it runs unchanged on PyTorch-ROCm.  All compute happens in the HIP library behind the C ABI
+(include/gs2d_rasterizer.h); torch only provides device memory and the current stream.
+"""
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+NUM_CHANNELS = 3
+
+
+def _ptr(t):
+    """Device pointer or NULL for empty tensors (the reference relies on empty tensors having a null data pointer,
+    rasterizer_impl.cu:327-328)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _check_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")  # rasterize_points.cu:27-28
+
+
+def _f32c(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+class _Chunk:
+    """Allocator callback target: the C side asks for N bytes, we hand out a torch uint8 tensor
+    (the resizeFunctional lambda of rasterize_points.cu:31-37)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.cb = _lib.ALLOC_FN(self._alloc)
+
+    def _alloc(self, _user, nbytes):
+        self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self.tensor.data_ptr()
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        use_sa, prefiltered, debug):
+    """_C.rasterize_gaussians (rasterize_points.cu:39-138): returns
+    (num_rendered, out_color[3,H,W], out_others[7,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer)."""
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    for name, t in (("background", background), ("means3D", means3D), ("colors", colors), ("opacity", opacity),
+                    ("scales", scales), ("rotations", rotations), ("transMat_precomp", transMat_precomp),
+                    ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("sh", sh), ("campos", campos)):
+        _check_cuda(t, name)
+    L = _lib.lib()
+    dev = means3D.device
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    out_color = torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    out_others = torch.zeros((7, H, W), dtype=torch.float32, device=dev)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    geom, binning, img = _Chunk(dev), _Chunk(dev), _Chunk(dev)
+    rendered = 0
+    if P != 0:
+        M = sh.size(1) if sh.size(0) != 0 else 0
+        keep = [_f32c(t) for t in (background, means3D, sh, colors, opacity, scales, rotations, transMat_precomp,
+                                   viewmatrix, projmatrix, campos)]
+        bg_, m3_, sh_, col_, op_, sc_, rot_, tm_, vm_, pm_, cp_ = keep
+        with torch.cuda.device(dev):
+            rendered = L.gs2d_forward(
+                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg_), W, H, _ptr(m3_),
+                _ptr(sh_), _ptr(col_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(tm_), _ptr(vm_),
+                _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), out_color.data_ptr(),
+                out_others.data_ptr(), radii.data_ptr(), int(bool(use_sa)), int(bool(debug)), _stream_ptr(dev))
+        if rendered < 0:
+            raise RuntimeError(_lib.last_error())
+    return rendered, out_color, out_others, radii, geom.tensor, binning.tensor, img.tensor
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                 transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                 dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, use_sa,
+                                 debug):
+    """_C.rasterize_gaussians_backward (rasterize_points.cu:140-239): returns
+    (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dtransMat[P,9], dL_dsh[P,M,3],
+     dL_dscales[P,2], dL_drotations[P,4])."""
+    for name, t in (("background", background), ("means3D", means3D), ("radii", radii), ("colors", colors),
+                    ("scales", scales), ("rotations", rotations), ("transMat_precomp", transMat_precomp),
+                    ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("sh", sh), ("campos", campos),
+                    ("binningBuffer", binningBuffer), ("imageBuffer", imageBuffer), ("geomBuffer", geomBuffer)):
+        _check_cuda(t, name)
+    L = _lib.lib()
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if sh.size(0) != 0 else 0
+    z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dnormal = z(P, 3), z(P, 3), z(P, NUM_CHANNELS), z(P, 3)
+    dL_dopacity, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations = z(P, 1), z(P, 9), z(P, M, 3), z(P, 2), z(P, 4)
+    if P != 0:
+        keep = [_f32c(t) for t in (background, means3D, sh, colors, scales, rotations, transMat_precomp, viewmatrix,
+                                   projmatrix, campos, dL_dout_color, dL_dout_others)]
+        bg_, m3_, sh_, col_, sc_, rot_, tm_, vm_, pm_, cp_, dc_, do_ = keep
+        radii_ = radii.contiguous()
+        with torch.cuda.device(dev):
+            rc = L.gs2d_backward(
+                P, int(degree), M, int(R), _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(sc_),
+                float(scale_modifier), _ptr(rot_), _ptr(tm_), _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx),
+                float(tan_fovy), radii_.data_ptr(), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+                dc_.data_ptr(), do_.data_ptr(), dL_dmeans2D.data_ptr(), dL_dnormal.data_ptr(), dL_dopacity.data_ptr(),
+                dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dtransMat.data_ptr(), _ptr(dL_dsh),
+                dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(use_sa)), int(bool(debug)), _stream_ptr(dev))
+        if rc < 0:
+            raise RuntimeError(_lib.last_error())
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """_C.mark_visible (rasterize_points.cu:241-260)."""
+    L = _lib.lib()
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P != 0:
+        m3_, vm_, pm_ = _f32c(means3D), _f32c(viewmatrix), _f32c(projmatrix)
+        with torch.cuda.device(means3D.device):
+            rc = L.gs2d_mark_visible(P, m3_.data_ptr(), vm_.data_ptr(), pm_.data_ptr(), present.data_ptr(),
+                                     _stream_ptr(means3D.device))
+        if rc < 0:
+            raise RuntimeError(_lib.last_error())
+    return present
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """RAST/gaus_2dgs_rasterization/__init__.py:44-161."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_gaussians(
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
+            rs.campos, rs.use_sa, rs.prefiltered, rs.debug)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                              binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth):
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
+         imgBuffer) = ctx.saved_tensors
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = rasterize_gaussians_backward(
+            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, sh, rs.sh_degree, rs.campos, geomBuffer,
+            ctx.num_rendered, binningBuffer, imgBuffer, rs.use_sa, rs.debug)
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, None)
+
+
+def rasterize_gaussians_apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                              raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    use_sa: bool
+    prefiltered: bool
+    debug: bool
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            return mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = lambda: torch.empty(0, dtype=torch.float32, device=means3D.device)
+        if shs is None:
+            shs = empty()
+        if colors_precomp is None:
+            colors_precomp = empty()
+        if scales is None:
+            scales = empty()
+        if rotations is None:
+            rotations = empty()
+        if cov3D_precomp is None:
+            cov3D_precomp = empty()
+        return rasterize_gaussians_apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                         cov3D_precomp, rs)

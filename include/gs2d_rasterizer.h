@@ -1,0 +1,135 @@
+/*
+ * gs2d_rasterizer.h -- C ABI of the MI355X-native 2D-Gaussian-surfel rasterizer.
+ *
+ * Drop-in boundary for the hot path of vasabi-root/gaus-slam.  Every entry
+ * point replaces one interface of the reference (paths relative to
+ * /root/reference, RAST = submodules/gaus_2dgs_rasterization):
+ *
+ *   gs2d_forward       <- CudaRasterizer::Rasterizer::forward
+ *                         RAST/cuda_rasterizer/rasterizer.h:42-71, rasterizer_impl.cu:201-350
+ *   gs2d_backward      <- CudaRasterizer::Rasterizer::backward
+ *                         RAST/cuda_rasterizer/rasterizer.h:73-107, rasterizer_impl.cu:354-460
+ *   gs2d_mark_visible  <- CudaRasterizer::Rasterizer::markVisible
+ *                         RAST/cuda_rasterizer/rasterizer.h:35-40, rasterizer_impl.cu:141-153
+ *   sknn_dist2         <- simple_knn._C.distCUDA2 (call sites scene/Gaussians.py:77,218;
+ *                         third-party module, source absent from the mounted reference)
+ *
+ * Conventions (identical to the reference unless stated):
+ *   - all pointers are DEVICE pointers to float32 / int32 data, plain C layouts;
+ *     NULL selects the alternative path exactly as the reference's nullptr does
+ *     (colors_precomp vs shs, scales+rotations vs transMat_precomp);
+ *   - viewmatrix / projmatrix are 16 floats, column-major (the transposed
+ *     matrices render/render_2dgs.py:10-24 builds);
+ *   - scratch memory is obtained through caller-supplied allocator callbacks
+ *     (the C form of the reference's std::function<char*(size_t)>); the three
+ *     chunks must stay alive, untouched, until the matching gs2d_backward;
+ *     their internal layout is private to this library (query it with the
+ *     gs2d_*_layout helpers, used by the parity tests only);
+ *   - `stream` is a hipStream_t (NULL = the null stream).  The reference used
+ *     the legacy default stream; callers here pass torch's current HIP stream;
+ *   - return value < 0 signals an error; gs2d_last_error() describes it.
+ *     (The reference throws std::runtime_error / AT_ERROR.)
+ *
+ * No torch types appear in this header.  The reference-side binding a
+ * maintainer would write is shown in INTEGRATION.md.
+ */
+#ifndef GS2D_RASTERIZER_H
+#define GS2D_RASTERIZER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Scratch allocator: must return a device pointer to >= `bytes` bytes, 256-byte aligned. */
+typedef void* (*gs2d_alloc_fn)(void* user, size_t bytes);
+
+/* Returns num_rendered (>= 0, number of (tile, Gaussian) instances) or < 0 on error.
+ * Performs one stream synchronisation (as the reference does, rasterizer_impl.cu:287). */
+int gs2d_forward(
+    gs2d_alloc_fn geometry_alloc, void* geometry_user,
+    gs2d_alloc_fn binning_alloc, void* binning_user,
+    gs2d_alloc_fn image_alloc, void* image_user,
+    int P, int D, int M,
+    const float* background,          /* [3] */
+    int width, int height,
+    const float* means3D,             /* [P,3] */
+    const float* shs,                 /* [P,M,3] or NULL */
+    const float* colors_precomp,      /* [P,3]  or NULL */
+    const float* opacities,           /* [P] */
+    const float* scales,              /* [P,2]  or NULL */
+    float scale_modifier,
+    const float* rotations,           /* [P,4] (w,x,y,z) or NULL */
+    const float* transMat_precomp,    /* [P,9]  or NULL */
+    const float* viewmatrix,          /* [16] column-major */
+    const float* projmatrix,          /* [16] column-major */
+    const float* cam_pos,             /* [3] */
+    float tan_fovx, float tan_fovy,
+    int prefiltered,
+    float* out_color,                 /* [3,H,W] */
+    float* out_others,                /* [7,H,W]: depth, alpha, normal xyz, median depth, dist */
+    int* radii,                       /* [P] */
+    int use_sa, int debug, void* stream);
+
+/* All dL_* outputs must be zero-initialised by the caller (rasterize_points.cu:192-200). */
+int gs2d_backward(
+    int P, int D, int M, int R,
+    const float* background,
+    int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp,
+    const float* scales, float scale_modifier, const float* rotations,
+    const float* transMat_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy,
+    const int* radii,
+    char* geom_buffer, char* binning_buffer, char* img_buffer,
+    const float* dL_dpix,             /* [3,H,W] */
+    const float* dL_depths,           /* [7,H,W] */
+    float* dL_dmean2D,                /* [P,3] */
+    float* dL_dnormal,                /* [P,3] */
+    float* dL_dopacity,               /* [P]   */
+    float* dL_dcolor,                 /* [P,3] */
+    float* dL_dmean3D,                /* [P,3] */
+    float* dL_dtransMat,              /* [P,9] */
+    float* dL_dsh,                    /* [P,M,3] */
+    float* dL_dscale,                 /* [P,2] */
+    float* dL_drot,                   /* [P,4] */
+    int use_sa, int debug, void* stream);
+
+/* present: [P] bytes (0/1). */
+int gs2d_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                      const float* projmatrix, uint8_t* present, void* stream);
+
+/* Mean squared distance to the 3 nearest other points; points [N,3], out [N].
+ * `ws_alloc` provides temporary device memory (may be freed after the stream drains). */
+int sknn_dist2(int N, const float* points, float* out,
+               gs2d_alloc_fn ws_alloc, void* ws_user, void* stream);
+
+/* Sizes of the three scratch chunks (what the allocator callbacks will be asked for). */
+size_t gs2d_geometry_bytes(int P);
+size_t gs2d_image_bytes(int width, int height);
+size_t gs2d_binning_bytes(int R);
+
+/*
+ * Private-layout introspection for the parity tests: byte offsets of the
+ * sub-arrays inside each chunk.  Geometry: [0] depths f32[P], [1] tiles_touched
+ * u32[P], [2] point_offsets u32[P], [3] splat records f32[P][20], [4] clamped
+ * u8[3P].  Binning: [0] point_list u32[R], [1] sorted keys u64[R].
+ * Image: [0] ranges u32[tiles][2], [1] pixel state f32/u32[7][tiles*256]
+ * (planes: T_final, M1, M2, median depth, depth std, last contributor, median
+ * contributor; element index = tile*256 + quadrant*64 + (y%8)*8 + (x%8) with
+ * quadrant = (y/8)*2 + (x/8) for pixel (x,y) inside its 16x16 tile).
+ */
+void gs2d_geometry_layout(int P, size_t offsets[5]);
+void gs2d_binning_layout(int R, size_t offsets[2]);
+void gs2d_image_layout(int width, int height, size_t offsets[2]);
+
+const char* gs2d_last_error(void);
+const char* gs2d_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

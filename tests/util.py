@@ -1,0 +1,111 @@
+"""Shared helpers for the parity tests: run the same seeded scene through the CPU oracle and through the HIP
+library (via the C ABI wrappers in gaus_slam_amd.rasterizer) and expose comparable views of both."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from gaus_slam_amd.scene_synth import make_scene, make_upstream_grads  # noqa: F401
+
+TILE = 16
+
+
+def oracle_forward(orc, sc, use_sa=True, bg=(0.0, 0.0, 0.0), shs=None, sh_degree=0, transMat_precomp=None,
+                   scale_modifier=1.0):
+    cam = sc["cam"]
+    kw = {}
+    if transMat_precomp is None:
+        kw.update(scales=sc["scales"].numpy(), rotations=sc["rotations"].numpy())
+    else:
+        kw.update(transMat_precomp=transMat_precomp)
+    if shs is None:
+        kw.update(colors_precomp=sc["colors"].numpy())
+    else:
+        kw.update(shs=shs, sh_degree=sh_degree)
+    return orc.forward(sc["means3D"].numpy(), sc["opacities"].numpy(), cam.viewmatrix.numpy(), cam.projmatrix.numpy(),
+                       cam.campos.numpy(), cam.W, cam.H, cam.tanfovx, cam.tanfovy, bg=bg, use_sa=use_sa,
+                       scale_modifier=scale_modifier, **kw)
+
+
+def pix_index_map(W, H):
+    """state index (tile*256 + quadrant*64 + (y%8)*8 + x%8) for every pixel, as [H,W] int64 (see
+    include/gs2d_rasterizer.h)."""
+    gx = (W + TILE - 1) // TILE
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    tile = (ys // TILE) * gx + (xs // TILE)
+    ly, lx = ys % TILE, xs % TILE
+    quad = (ly // 8) * 2 + (lx // 8)
+    return tile * 256 + quad * 64 + (ly % 8) * 8 + (lx % 8)
+
+
+def hip_forward(sc, use_sa=True, bg=(0.0, 0.0, 0.0), shs=None, sh_degree=0, transMat_precomp=None, scale_modifier=1.0,
+                debug=False, device="cuda"):
+    """Calls the C-ABI forward through gaus_slam_amd.rasterizer.rasterize_gaussians and unpacks the private
+    scratch layout for comparison."""
+    from gaus_slam_amd import _lib, rasterizer
+    cam = sc["cam"]
+    dev = torch.device(device)
+    e = torch.empty(0, dtype=torch.float32, device=dev)
+    t = lambda a: (torch.as_tensor(a).float().to(dev).contiguous() if a is not None else e)
+    means3D, opac = t(sc["means3D"]), t(sc["opacities"])
+    colors = t(sc["colors"]) if shs is None else e
+    sh = t(shs) if shs is not None else e
+    scales = t(sc["scales"]) if transMat_precomp is None else e
+    rots = t(sc["rotations"]) if transMat_precomp is None else e
+    tm = t(transMat_precomp) if transMat_precomp is not None else e
+    args = (t(np.asarray(bg, np.float32)), means3D, colors, opac, scales, rots, scale_modifier, tm,
+            t(cam.viewmatrix), t(cam.projmatrix), cam.tanfovx, cam.tanfovy, cam.H, cam.W, sh, sh_degree,
+            t(cam.campos), use_sa, False, debug)
+    R, color, allmap, radii, geom, binning, img = rasterizer.rasterize_gaussians(*args)
+    torch.cuda.synchronize()
+    L = _lib.lib()
+    P, W, H = means3D.shape[0], cam.W, cam.H
+    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    go = (C.c_size_t * 5)(); bo = (C.c_size_t * 2)(); io = (C.c_size_t * 2)()
+    L.gs2d_geometry_layout(P, go); L.gs2d_binning_layout(R, bo); L.gs2d_image_layout(W, H, io)
+    g = geom.cpu().numpy(); b = binning.cpu().numpy(); im = img.cpu().numpy()
+    view = lambda buf, off, dt, n: np.frombuffer(buf.tobytes()[off:off + n * np.dtype(dt).itemsize], dtype=dt)
+    out = dict(num_rendered=R, color=color.cpu().numpy(), allmap=allmap.cpu().numpy(), radii=radii.cpu().numpy(),
+               args=args, buffers=(geom, binning, img))
+    if P > 0:
+        out["depths"] = view(g, go[0], np.float32, P)
+        out["tiles_touched"] = view(g, go[1], np.uint32, P)
+        out["point_offsets"] = view(g, go[2], np.uint32, P)
+        out["rec"] = view(g, go[3], np.float32, P * 20).reshape(P, 20)
+        out["clamped"] = view(g, go[4], np.uint8, P * 3).reshape(P, 3)
+        out["point_list"] = view(b, bo[0], np.uint32, R) if R > 0 else np.zeros(0, np.uint32)
+        out["keys"] = view(b, bo[1], np.uint64, R) if R > 0 else np.zeros(0, np.uint64)
+        out["ranges"] = view(im, io[0], np.uint32, gx * gy * 2).reshape(gx * gy, 2)
+        plane = gx * gy * 256
+        ps = view(im, io[1], np.float32, 7 * plane).reshape(7, plane)
+        idx = pix_index_map(W, H)
+        out["final_T"] = ps[0][idx]; out["M1"] = ps[1][idx]; out["M2"] = ps[2][idx]
+        out["median_depth"] = ps[3][idx]; out["depth_std"] = ps[4][idx]
+        psu = ps.view(np.uint32)
+        out["last_contributor"] = psu[5][idx]; out["median_contributor"] = psu[6][idx]
+    return out
+
+
+def hip_backward(fw, dL_dcolor, dL_dallmap, device="cuda"):
+    from gaus_slam_amd import rasterizer
+    a = fw["args"]
+    geom, binning, img = fw["buffers"]
+    dev = torch.device(device)
+    dc = torch.as_tensor(dL_dcolor).float().to(dev).contiguous()
+    da = torch.as_tensor(dL_dallmap).float().to(dev).contiguous()
+    radii = torch.as_tensor(fw["radii"]).to(dev)
+    res = rasterizer.rasterize_gaussians_backward(
+        a[0], a[1], radii, a[2], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], dc, da, a[14], a[15], a[16], geom,
+        fw["num_rendered"], binning, img, a[17], a[19])
+    torch.cuda.synchronize()
+    names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dtransMat", "dL_dsh", "dL_dscales",
+             "dL_drotations"]
+    return {n: r.cpu().numpy() for n, r in zip(names, res)}
+
+
+def grad_err(a, b):
+    """max |a-b| normalised by max |b| (per tensor)."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    if b.size == 0:
+        return 0.0
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
