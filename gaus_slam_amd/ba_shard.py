@@ -1,0 +1,105 @@
+"""Keyframe-sharded bundle adjustment step: one process per GPU, one keyframe per rank, one all-reduce of the
+Gaussian gradients over RCCL/xGMI.
+
+The reference is strictly one keyframe per optimizer step on one GPU (slam/Backend.py:101-128,174-194); this
+mini-batch formulation is new.  Every rank holds a full replica of the Gaussian SoA; rank r renders
+keyframe r of the batch with the single-GPU op (fwd+bwd), the five parameter gradients are packed into ONE flat
+fp32 bucket of 13 floats per Gaussian (xyz 3 | opacity 1 | scaling 2 | rotation 4 | rgb 3 -- the param groups of
+scene/Gaussians.py:124-135) and summed with a single all-reduce.  World size 1 skips the collective, so K=1
+reproduces the single-GPU path bit for bit.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+
+# name -> floats per Gaussian, in bucket order
+BUCKET_FIELDS = OrderedDict([("means3D", 3), ("opacities", 1), ("scales", 2), ("rotations", 4), ("colors", 3)])
+BUCKET_FLOATS = sum(BUCKET_FIELDS.values())  # 13
+
+
+class GradBucket:
+    """Flat [13*P] fp32 buffer; each field is a contiguous [P,k] view (SoA segments, so packing a gradient is one
+    contiguous copy and the collective is one large message: xGMI is per-link bound, fewer/larger is better)."""
+
+    def __init__(self, P, device):
+        self.P = P
+        self.flat = torch.zeros(BUCKET_FLOATS * P, dtype=torch.float32, device=device)
+        self.views = OrderedDict()
+        o = 0
+        for name, k in BUCKET_FIELDS.items():
+            self.views[name] = self.flat[o:o + k * P].view(P, k)
+            o += k * P
+
+    def pack(self, grads):
+        for name, v in self.views.items():
+            g = grads.get(name)
+            if g is None:
+                v.zero_()
+            else:
+                v.copy_(g.reshape(v.shape))
+
+    def all_reduce(self, group=None, average=False):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            if average:
+                self.flat.div_(dist.get_world_size(group))
+        return self.flat
+
+
+def shard_keyframes(keyframes, rank, world_size):
+    """Keyframe k of the batch goes to rank k % world_size (independent units, no data-path exchange)."""
+    return [kf for i, kf in enumerate(keyframes) if i % world_size == rank]
+
+
+class KeyframeShardedBA:
+    """params: dict name -> leaf tensor (requires_grad) with the BUCKET_FIELDS names.
+    render_loss_fn(params, keyframe) -> scalar loss OR (outputs, upstream_grads) pair for torch.autograd.backward.
+    """
+
+    def __init__(self, params, render_loss_fn, group=None, average=False):
+        self.params = params
+        self.fn = render_loss_fn
+        self.group = group
+        self.average = average
+        P = params["means3D"].shape[0]
+        self.bucket = GradBucket(P, params["means3D"].device)
+
+    @property
+    def world_size(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    @property
+    def rank(self):
+        return dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
+
+    def local_backward(self, keyframe):
+        for p in self.params.values():
+            p.grad = None
+        res = self.fn(self.params, keyframe)
+        if isinstance(res, tuple):
+            outs, ups = res
+            torch.autograd.backward(list(outs), list(ups))
+        else:
+            res.backward()
+        return {k: p.grad for k, p in self.params.items()}
+
+    def step(self, keyframes):
+        """One BA step over a batch of keyframes (len == world_size in the bench; ragged batches allowed: ranks
+        without a keyframe contribute zeros).  Returns the reduced bucket views (name -> [P,k])."""
+        mine = shard_keyframes(keyframes, self.rank, self.world_size)
+        if not mine:
+            self.bucket.flat.zero_()
+        else:
+            acc = None
+            for kf in mine:
+                g = self.local_backward(kf)
+                if acc is None:
+                    self.bucket.pack(g)
+                    acc = True
+                else:
+                    for name, v in self.bucket.views.items():
+                        if g.get(name) is not None:
+                            v.add_(g[name].reshape(v.shape))
+        self.bucket.all_reduce(self.group, self.average)
+        return self.bucket.views

@@ -51,6 +51,32 @@ uint32_t higher_msb(uint32_t n)
     return msb;
 }
 
+// Optional per-stage device timing (hipEvents recorded on the SAME stream the kernels are launched on).
+// Used by bench.py for the per-kernel roofline; off by default (no events are created or recorded).
+enum { ST_PREPROCESS = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_COUNT };
+struct StageTimer {
+    bool enabled = false;
+    hipEvent_t ev[ST_COUNT][2];
+    bool have_ev = false;
+    bool recorded[ST_COUNT] = {};
+    void begin(int st, hipStream_t s)
+    {
+        if (!enabled) return;
+        if (!have_ev) {
+            for (int i = 0; i < ST_COUNT; i++) { (void)hipEventCreate(&ev[i][0]); (void)hipEventCreate(&ev[i][1]); }
+            have_ev = true;
+        }
+        (void)hipEventRecord(ev[st][0], s);
+    }
+    void end(int st, hipStream_t s)
+    {
+        if (!enabled) return;
+        (void)hipEventRecord(ev[st][1], s);
+        recorded[st] = true;
+    }
+};
+StageTimer g_timer;
+
 // pinned host word for the num_rendered read-back (one per host thread)
 struct PinnedWord {
     uint32_t* p = nullptr;
@@ -63,6 +89,27 @@ thread_local PinnedWord g_pinned;
 extern "C" {
 
 const char* gs2d_last_error(void) { return g_err.c_str(); }
+
+void gs2d_stage_timing_enable(int on)
+{
+    g_timer.enabled = on != 0;
+    for (int i = 0; i < ST_COUNT; i++) g_timer.recorded[i] = false;
+}
+
+// ms[8]: preprocess, scan, duplicate, sort, ranges, blend_fwd, blend_bwd, preprocess_bwd of the most recent calls
+// (-1 where nothing was recorded).  Synchronises on the recorded events.
+int gs2d_stage_timing_read(float ms[8])
+{
+    for (int i = 0; i < ST_COUNT; i++) {
+        ms[i] = -1.f;
+        if (!g_timer.recorded[i]) continue;
+        if (hipEventSynchronize(g_timer.ev[i][1]) != hipSuccess) return -1;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_timer.ev[i][0], g_timer.ev[i][1]) != hipSuccess) return -1;
+        ms[i] = t;
+    }
+    return 0;
+}
 
 const char* gs2d_build_info(void) { return "gs2d-hip gfx950 strict-fp (fp-contract=off) " __DATE__; }
 
@@ -124,13 +171,17 @@ int gs2d_forward(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_alloc_f
     uint8_t* clamped = (uint8_t*)(geom + GL.clamped);
     uint32_t* scan_tmp = (uint32_t*)(geom + GL.scan_tmp);
 
+    g_timer.begin(ST_PREPROCESS, s);
     gs2d::launch_preprocess_fwd(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, transMat_precomp,
                                 colors_precomp, cam, radii, depths, rec, tiles_touched, clamped, s);
+    g_timer.end(ST_PREPROCESS, s);
     GS2D_STAGE("preprocess");
 
     const int nblk = (P + GS2D_SCAN_ITEMS - 1) / GS2D_SCAN_ITEMS;
     uint32_t* total_dev = scan_tmp + nblk + 8;
+    g_timer.begin(ST_SCAN, s);
     gs2d::launch_inclusive_scan(tiles_touched, point_offsets, P, scan_tmp, total_dev, s);
+    g_timer.end(ST_SCAN, s);
     GS2D_STAGE("scan");
 
     // The one host sync of the forward (rasterizer_impl.cu:287): the binning chunk is sized by num_rendered.
@@ -158,15 +209,23 @@ int gs2d_forward(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_alloc_f
         // unsorted pairs go where the ping-pong needs them so that the result lands in (keys, point_list)
         uint64_t* k_unsorted = (passes & 1) ? keys_alt : keys;
         uint32_t* v_unsorted = (passes & 1) ? vals_alt : point_list;
+        g_timer.begin(ST_DUPLICATE, s);
         gs2d::launch_duplicate(P, rec, depths, point_offsets, radii, cam.gx, cam.gy, k_unsorted, v_unsorted, s);
+        g_timer.end(ST_DUPLICATE, s);
         GS2D_STAGE("duplicate");
+        g_timer.begin(ST_SORT, s);
         gs2d::launch_sort_pairs(R, keys, point_list, keys_alt, vals_alt, end_bit, hist, BL.hist_elems, s);
+        g_timer.end(ST_SORT, s);
         GS2D_STAGE("sort");
     }
+    g_timer.begin(ST_RANGES, s);
     gs2d::launch_tile_ranges(R, keys, ranges, IL.tiles, s);
+    g_timer.end(ST_RANGES, s);
     GS2D_STAGE("ranges");
+    g_timer.begin(ST_BLEND_FWD, s);
     gs2d::launch_blend_fwd(width, height, ranges, point_list, rec, background, out_color, out_others, pix_state,
                            use_sa, s);
+    g_timer.end(ST_BLEND_FWD, s);
     GS2D_STAGE("blend_fwd");
     return R;
 }
@@ -196,8 +255,10 @@ int gs2d_backward(int P, int D, int M, int R, const float* background, int width
 
     GS2D_CHECK(hipMemsetAsync(grad_rec, 0, sizeof(float) * GS2D_GRAD_FLOATS * (size_t)P, s), "memset grad_rec");
     if (R > 0) {
+        g_timer.begin(ST_BLEND_BWD, s);
         gs2d::launch_blend_bwd(width, height, ranges, point_list, rec, background, pix_state, dL_dpix, dL_depths,
                                grad_rec, use_sa, s);
+        g_timer.end(ST_BLEND_BWD, s);
         GS2D_STAGE("blend_bwd");
     }
     // rasterizer_impl.cu:396-397 + backward.cu:641-642: the backward rebuilds W,H from focal*tan in float32
@@ -209,9 +270,11 @@ int gs2d_backward(int P, int D, int M, int R, const float* background, int width
     cam.H = (int)(focal_y * tan_fovy * 2);
     cam.gx = (width + GS2D_TILE - 1) / GS2D_TILE;
     cam.gy = (height + GS2D_TILE - 1) / GS2D_TILE;
+    g_timer.begin(ST_PREPROCESS_BWD, s);
     gs2d::launch_preprocess_bwd(P, D, M, means3D, rec, radii, shs, clamped, scales, rotations, cam, grad_rec,
                                 dL_dtransMat, dL_dnormal, dL_dcolor, dL_dopacity, dL_dsh, dL_dmean2D, dL_dmean3D,
                                 dL_dscale, dL_drot, s);
+    g_timer.end(ST_PREPROCESS_BWD, s);
     GS2D_STAGE("preprocess_bwd");
     return 0;
 }

@@ -4,13 +4,14 @@
 // Design (gfx950, wave64):
 //   * one workgroup per 16x16 tile, 4 waves, each wave owns an 8x8 pixel quadrant (compact footprint ->
 //     coherent per-wave skip / early-out decisions);
-//   * the tile's depth-sorted splat list is staged through LDS in batches of packed 80-byte splat
-//     records (5 x ds_write_b128 per splat), then read back as wave-uniform broadcasts;
+//   * the tile's depth-sorted splat list is consumed in batches of 64: each lane keeps one packed 80-byte
+//     splat record in registers, a conservative cull test per quadrant is ballot-ed into a 64-bit mask, and the
+//     wave walks the set bits broadcasting the record with v_readlane (no LDS, no barrier in the loops);
 //   * forward: the 4 waves run independently (no workgroup barrier in the loop; a wave leaves as soon as
 //     its 64 pixels are saturated);
-//   * backward: per-(pixel,splat) gradients are summed over the 64 lanes with DPP row/bcast adds, combined
-//     across the 4 waves in LDS, and flushed with ONE global atomic per (tile, splat, component) --
-//     the reference issues one per (pixel, splat, component).
+//   * backward: per-(pixel,splat) gradients are summed over the 64 lanes with a 16-value permlane/DPP butterfly
+//     and flushed with ONE packed global atomic instruction per contributing (quadrant, splat) --
+//     the reference issues 16-18 scalar atomics per (pixel, splat).
 // Arithmetic follows the oracle's expression order; the file is compiled with -ffp-contract=off so the
 // per-pixel recurrences reproduce the CPU oracle up to the ulp-level difference of expf.
 #include "gs2d_common.h"
@@ -25,62 +26,110 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ------------------------------------------------------------------------------------------- helpers
+__device__ __forceinline__ float bcast(float v, int lane)  // wave-uniform broadcast of lane `lane` (v_readlane_b32)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }          // v_rcp_f32, 1 ulp
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }  // v_exp_f32
+
+// Conservative screen-space bound of the pixels a splat can touch with alpha >= 1/255, evaluated by the lane
+// that holds the splat record.  rho_max = 2 ln(255 opacity) (+margin, precomputed by the preprocess kernel):
+//   alpha >= 1/255  <=>  min(rho3d, rho2d) <= rho_max
+// {rho3d <= rho_max} is the projection of the disc u^2+v^2 <= rho_max of the surfel; when that disc lies
+// safely in front of the eye its image is an ellipse whose exact AABB follows from the same closed form the
+// reference uses for its 3-sigma box (forward.cu:119-147) with cutoff^2 = rho_max; {rho2d <= rho_max} is a
+// disc of radius sqrt(rho_max/100) px around the stored centre.  Anything that cannot be bounded safely is kept.
+// Returns true when the splat may touch the pixel rectangle [x0,x1] x [y0,y1].
+__device__ __forceinline__ bool splat_may_touch(const float4 q0, const float4 q1, const float4 q2, float rho_max,
+                                                float x0, float x1, float y0, float y1)
+{
+    if (!(rho_max >= 0.f)) return false;  // opacity*G can never reach 1/255 (rho_max < 0; NaN opacity is encoded as +huge)
+    const float rl = sqrtf(rho_max * (1.0f / GS2D_FILTER_INV_SQ)) + 0.5f;
+    float bx0 = q0.w - rl, bx1 = q0.w + rl, by0 = q1.w - rl, by1 = q1.w + rl;
+    const float a = rho_max * (q2.x * q2.x + q2.y * q2.y), zz = q2.z * q2.z;
+    if (!(a <= 0.9f * zz) || !(q2.z > 0.f)) return true;  // disc not safely in front of the eye: no bound
+    const float inv = 1.0f / (a - zz);
+    const float f0 = rho_max * inv, f2 = -inv;
+    const float cx = f0 * (q0.x * q2.x + q0.y * q2.y) + f2 * (q0.z * q2.z);
+    const float cy = f0 * (q1.x * q2.x + q1.y * q2.y) + f2 * (q1.z * q2.z);
+    const float hx = cx * cx - (f0 * (q0.x * q0.x + q0.y * q0.y) + f2 * (q0.z * q0.z));
+    const float hy = cy * cy - (f0 * (q1.x * q1.x + q1.y * q1.y) + f2 * (q1.z * q1.z));
+    if (!(hx == hx) || !(hy == hy)) return true;
+    const float ex = sqrtf(fmaxf(hx, 0.f)), ey = sqrtf(fmaxf(hy, 0.f));
+    const float mx = 0.5f + 0.02f * ex + 1e-4f * fabsf(cx), my = 0.5f + 0.02f * ey + 1e-4f * fabsf(cy);
+    bx0 = fminf(bx0, cx - ex - mx); bx1 = fmaxf(bx1, cx + ex + mx);
+    by0 = fminf(by0, cy - ey - my); by1 = fmaxf(by1, cy + ey + my);
+    return !(bx1 < x0 || bx0 > x1 || by1 < y0 || by0 > y1);
+}
+
 // ------------------------------------------------------------------------------------------- forward
+// One wave per 8x8 pixel quadrant, 4 independent waves per 16x16 tile.  Each lane keeps ONE splat record of the
+// current 64-splat batch in registers; the wave walks the set bits of the cull mask and broadcasts the record of
+// splat j with v_readlane (SGPR operands): no LDS, no barrier, no memory latency inside the per-splat loop.
 template <bool USE_SA>
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
                  float* __restrict__ out_others, float* __restrict__ pix_state, size_t plane)
 {
-    __shared__ float4 sm[4][GS2D_REC_F4][64];
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
-    const int px = tx * GS2D_TILE + lx, py = ty * GS2D_TILE + ly;
+    const int qx0 = tx * GS2D_TILE + (wave & 1) * 8, qy0 = ty * GS2D_TILE + (wave >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
+    const float fx0 = (float)qx0, fx1 = (float)(qx0 + 7), fy0 = (float)qy0, fy1 = (float)(qy0 + 7);
     const uint2 range = ranges[tile];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
     float Dp = 0.f, M1 = 0.f, M2 = 0.f, D2 = 0.f, distortion = 0.f, median_depth = 0.f;
-    uint32_t median_contributor = 0;  // the reference keeps a float initialised to -1 and stores (uint)-> 0
+    uint32_t median_contributor = 0;  // the reference keeps a float initialised to -1 and stores (uint) -> 0
     uint32_t last_contributor = 0;
     bool done = !inside;
 
     for (uint32_t base = range.x; base < range.y; base += 64) {
         if (__ballot(!done) == 0) break;
         const int n = min(64, (int)(range.y - base));
+        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0, r4 = r0;
+        bool touch = false;
         if (lane < n) {
             const uint32_t id = point_list[base + lane];
             const float4* rp = rec + (size_t)id * GS2D_REC_F4;
-#pragma unroll
-            for (int k = 0; k < GS2D_REC_F4; k++) sm[wave][k][lane] = rp[k];
+            r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4];
+            touch = splat_may_touch(r0, r1, r2, r4.z, fx0, fx1, fy0, fy1);
         }
-        wave_lds_fence();
-        for (int j = 0; j < n; j++) {
+        uint64_t mask = __ballot(touch);
+        while (mask) {
             if (__ballot(!done) == 0) break;
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const float Tux = bcast(r0.x, j), Tuy = bcast(r0.y, j), Tuz = bcast(r0.z, j), cxy0 = bcast(r0.w, j);
+            const float Tvx = bcast(r1.x, j), Tvy = bcast(r1.y, j), Tvz = bcast(r1.z, j), cxy1 = bcast(r1.w, j);
+            const float Twx = bcast(r2.x, j), Twy = bcast(r2.y, j), Twz = bcast(r2.z, j), opa = bcast(r2.w, j);
             if (!done) {
                 const uint32_t contributor = (base - range.x) + (uint32_t)j + 1u;
-                const float4 q0 = sm[wave][0][j], q1 = sm[wave][1][j], q2 = sm[wave][2][j];
-                // forward.cu:360-371
-                const float k0 = pxf * q2.x - q0.x, k1 = pxf * q2.y - q0.y, k2 = pxf * q2.z - q0.z;
-                const float l0 = pyf * q2.x - q1.x, l1 = pyf * q2.y - q1.y, l2 = pyf * q2.z - q1.z;
-                const float p0 = k1 * l2 - k2 * l1;
-                const float p1 = k2 * l0 - k0 * l2;
-                const float p2 = k0 * l1 - k1 * l0;
+                // forward.cu:360-371 (FMA form, identical to oracle/gs2d_oracle.c)
+                const float k0 = fmaf(pxf, Twx, -Tux), k1 = fmaf(pxf, Twy, -Tuy), k2 = fmaf(pxf, Twz, -Tuz);
+                const float l0 = fmaf(pyf, Twx, -Tvx), l1 = fmaf(pyf, Twy, -Tvy), l2 = fmaf(pyf, Twz, -Tvz);
+                const float p0 = fmaf(k1, l2, -(k2 * l1));
+                const float p1 = fmaf(k2, l0, -(k0 * l2));
+                const float p2 = fmaf(k0, l1, -(k1 * l0));
                 if (p2 == 0.0f) continue;
-                const float s0 = p0 / p2, s1 = p1 / p2;
-                const float rho3d = s0 * s0 + s1 * s1;
-                const float d0 = q0.w - pxf, d1 = q1.w - pyf;
-                const float rho2d = GS2D_FILTER_INV_SQ * (d0 * d0 + d1 * d1);
+                const float ip = fast_rcp(p2);
+                const float s0 = p0 * ip, s1 = p1 * ip;
+                const float rho3d = fmaf(s0, s0, s1 * s1);
+                const float d0 = cxy0 - pxf, d1 = cxy1 - pyf;
+                const float rho2d = GS2D_FILTER_INV_SQ * fmaf(d0, d0, d1 * d1);
                 const float rho = fminf(rho3d, rho2d);
-                float depth = (rho3d <= rho2d) ? (s0 * q2.x + s1 * q2.y) + q2.z : q2.z;
+                float depth = (rho3d <= rho2d) ? fmaf(s0, Twx, fmaf(s1, Twy, Twz)) : Twz;
                 if (depth < GS2D_NEAR_N) continue;
                 const float power = -0.5f * rho;
                 if (power > 0.0f) continue;
-                const float alpha = fminf(0.99f, q2.w * expf(power));
+                const float alpha = fminf(0.99f, opa * fast_exp(power));
                 if (alpha < 1.0f / 255.0f) continue;
                 const float test_T = T * (1 - alpha);
                 if (test_T < 0.0001f) { done = true; continue; }
@@ -89,45 +138,43 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                 if (USE_SA) {  // forward.cu:405-416
                     if (Dp > 0) {
                         const float exp_depth = median_depth;
-                        float exp_std = (D2 - 2 * Dp * exp_depth) / (1 - T) + exp_depth * exp_depth;
+                        float exp_std = fmaf(fmaf(-2.0f * Dp, exp_depth, D2), fast_rcp(1 - T), exp_depth * exp_depth);
                         exp_std = fmaxf(exp_std, 1e-7f);
-                        const float error = (exp_depth - depth) * (exp_depth - depth);
-                        const float conf = expf(-error / (4 * exp_std));
-                        depth = conf * depth + (1 - conf) * exp_depth;
+                        const float e = exp_depth - depth;
+                        const float conf = fast_exp(-(e * e) * fast_rcp(4 * exp_std));
+                        depth = fmaf(conf, depth, (1 - conf) * exp_depth);
                     }
-                    Dp += depth * w;
-                    D2 += depth * depth * w;
+                    Dp = fmaf(depth, w, Dp);
+                    D2 = fmaf(depth * depth, w, D2);
                 } else {  // forward.cu:417-423
                     const float A = 1 - T;
-                    const float m = GS2D_FAR_N / (GS2D_FAR_N - GS2D_NEAR_N) * (1 - GS2D_NEAR_N / depth);
-                    distortion += (m * m * A + M2 - 2 * m * M1) * w;
-                    Dp += depth * w;
-                    M1 += m * w;
-                    M2 += m * m * w;
+                    const float m = (GS2D_FAR_N / (GS2D_FAR_N - GS2D_NEAR_N)) * (1 - GS2D_NEAR_N * fast_rcp(depth));
+                    distortion = fmaf(fmaf(m * m, A, fmaf(-2.0f * m, M1, M2)), w, distortion);
+                    Dp = fmaf(depth, w, Dp);
+                    M1 = fmaf(m, w, M1);
+                    M2 = fmaf(m * m, w, M2);
                 }
-                const float4 q3 = sm[wave][3][j], q4 = sm[wave][4][j];
-                N0 += q3.x * w; N1 += q3.y * w; N2 += q3.z * w;
-                C0 += q3.w * w; C1 += q4.x * w; C2 += q4.y * w;
+                N0 = fmaf(bcast(r3.x, j), w, N0); N1 = fmaf(bcast(r3.y, j), w, N1); N2 = fmaf(bcast(r3.z, j), w, N2);
+                C0 = fmaf(bcast(r3.w, j), w, C0); C1 = fmaf(bcast(r4.x, j), w, C1); C2 = fmaf(bcast(r4.y, j), w, C2);
                 T = test_T;
                 last_contributor = contributor;
             }
         }
-        wave_lds_fence();
     }
     if (inside) {  // forward.cu:441-466
         const size_t HW = (size_t)H * W;
         const size_t pix = (size_t)W * py + px;
-        out_color[pix] = C0 + T * bg0;
-        out_color[HW + pix] = C1 + T * bg1;
-        out_color[2 * HW + pix] = C2 + T * bg2;
-        const float dstd = D2 - 2 * median_depth * Dp + median_depth * median_depth * (1 - T);
+        out_color[pix] = fmaf(T, bg0, C0);
+        out_color[HW + pix] = fmaf(T, bg1, C1);
+        out_color[2 * HW + pix] = fmaf(T, bg2, C2);
+        const float dstd = fmaf(median_depth * median_depth, 1 - T, fmaf(-2.0f * median_depth, Dp, D2));
         out_others[pix] = Dp;
         out_others[HW + pix] = 1 - T;
         out_others[2 * HW + pix] = N0;
         out_others[3 * HW + pix] = N1;
         out_others[4 * HW + pix] = N2;
         out_others[5 * HW + pix] = median_depth;
-        out_others[6 * HW + pix] = USE_SA ? D2 - 2 * median_depth * Dp + (1 - T) * median_depth * median_depth : distortion;
+        out_others[6 * HW + pix] = USE_SA ? dstd : distortion;
         const size_t si = (size_t)tile * GS2D_TILE_PIX + threadIdx.x;  // wave-major: coalesced 256-B rows
         pix_state[PS_TFINAL * plane + si] = T;
         pix_state[PS_M1 * plane + si] = M1;
@@ -140,23 +187,76 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 }
 
 // ------------------------------------------------------------------------------------------ backward
-// Sum over the 64 lanes of a wave; the total is valid in lane 63.
+// Plain 64-lane sum, total valid in lane 63 (used only on the rare low-pass branch).
 __device__ __forceinline__ float wave_sum_to_lane63(float v)
 {
-    // inclusive prefix inside each row of 16 (row_shr 1,2,4,8 with zero fill) ...
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
-    // ... then row_bcast15 into rows 1,3 and row_bcast31 into rows 2,3
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
     return v;
 }
 
-constexpr int BWD_BATCH = 128;
-constexpr int ACC_STRIDE = 20;
+// --- 16-value butterfly: sums 16 per-lane values over the 64 lanes in ~35 VALU ops instead of 16 x 6.
+// Each step halves the number of live registers: lanes keep one half of the values and receive the partner's
+// partial sums for that half.  Steps: v_permlane32_swap (lane ^ 32), v_permlane16_swap (row pairs), then DPP
+// row_mirror / row_half_mirror / quad_perm inside a row.
+__device__ __forceinline__ float swapadd32(float a, float b)  // lanes 0-31: a[l]+a[l+32]; lanes 32-63: b[l-32]+b[l]
+{
+    // v_permlane32_swap: a.hi <-> b.lo.  Inline asm because the ROCm 7.2 builtin drops its second result
+    // (scripts/dev/swap_probe.hip); hipcc adds no wait states around asm, so the nops live in the string.
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float swapadd16(float a, float b)  // even rows: a (row r + row r+1); odd rows: b
+{
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// pick(hi) ? b : a   kept by this lane, the other one is what the partner lane needs
+template <int CTRL>
+__device__ __forceinline__ float seladd(float a, float b, bool hi)
+{
+    const float keep = hi ? b : a, give = hi ? a : b;
+    return keep + dpp_get<CTRL>(give);
+}
+// After reduce16 every lane l holds the 64-lane total of value number
+//   idx(l) = 8*bit2(l) + 4*bit3(l) + 2*bit4(l) + bit5(l)        (bits 0,1 of l are don't-care)
+__device__ __forceinline__ float reduce16(const float v[16], int lane)
+{
+    float c[8], d[4], e[2];
+#pragma unroll
+    for (int i = 0; i < 8; i++) c[i] = swapadd32(v[2 * i], v[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) d[i] = swapadd16(c[2 * i], c[2 * i + 1]);
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+    e[0] = seladd<0x140>(d[0], d[1], b3);  // row_mirror: l <-> 15-l flips bit 3
+    e[1] = seladd<0x140>(d[2], d[3], b3);
+    float f = seladd<0x141>(e[0], e[1], b2);  // row_half_mirror: l <-> 7-l flips bit 2
+    f += dpp_get<0x4E>(f);                    // quad_perm [2,3,0,1]
+    f += dpp_get<0xB1>(f);                    // quad_perm [1,0,3,2]
+    return f;
+}
+// value number held by lane l after reduce16
+__device__ __forceinline__ int reduce16_index(int lane)
+{
+    return 8 * ((lane >> 2) & 1) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
+}
 
+// Gradient record (GS2D_GRAD_FLOATS = 20 floats per Gaussian):
+//   [0..2] dL_dcolor  [3..5] dL_dnormal  [6..14] dL_dT (Tu,Tv,Tw)  [15] dL_dopacity  [16,17] dL_dmean2D.xy
+//
+// One wave per 8x8 quadrant, waves independent (no LDS, no barrier).  Per contributing (wave, splat) pair the 16
+// main components are reduced with the butterfly above and added with ONE global atomic instruction whose 16
+// active lanes cover 64 contiguous bytes of the Gaussian's record (the reference issues 16-18 atomics per
+// (pixel, splat) pair).
 template <bool USE_SA>
 __global__ void __launch_bounds__(256)
 blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -164,26 +264,18 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                  size_t plane, const float* __restrict__ dL_dpix, const float* __restrict__ dL_dothers,
                  float* __restrict__ grad_rec)
 {
-    __shared__ float4 sm[GS2D_REC_F4][BWD_BATCH];
-    __shared__ uint32_t sm_id[BWD_BATCH];
-    __shared__ float acc[BWD_BATCH * ACC_STRIDE];
-    __shared__ uint32_t s_max_last;
-
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
-    const int px = tx * GS2D_TILE + lx, py = ty * GS2D_TILE + ly;
+    const int qx0 = tx * GS2D_TILE + (wave & 1) * 8, qy0 = ty * GS2D_TILE + (wave >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
+    const float fx0 = (float)qx0, fx1 = (float)(qx0 + 7), fy0 = (float)qy0, fy1 = (float)(qy0 + 7);
     const uint2 range = ranges[tile];
-    const uint32_t total = range.y - range.x;
     const size_t HW = (size_t)H * W;
     const size_t pix = (size_t)W * py + px;
-    const size_t si = (size_t)tile * GS2D_TILE_PIX + threadIdx.x;  // wave-major: coalesced 256-B rows
-
-    if (threadIdx.x == 0) s_max_last = 0;
-    __syncthreads();
+    const size_t si = (size_t)tile * GS2D_TILE_PIX + threadIdx.x;
 
     // backward.cu:197-248
     const float T_final = inside ? pix_state[PS_TFINAL * plane + si] : 0.f;
@@ -205,160 +297,159 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         final_D2 = pix_state[PS_M2 * plane + si];
     }
     const float final_A = 1 - T_final;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    const float bg_dot_dpixel = (bg0 * dpx0 + bg1 * dpx1) + bg2 * dpx2;
+    const float bg_dot = fmaf(bg[2], dpx2, fmaf(bg[1], dpx1, bg[0] * dpx0));
+    const float sa_k = 1.0f / (4 * fmaxf(mstd * (1.0f / (1 - T_final)), 1e-7f));  // per-pixel constant (IEEE, as the oracle)
+    const float c1 = GS2D_FAR_N / (GS2D_FAR_N - GS2D_NEAR_N);
     float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
     float last_depth = 0.f, ln0 = 0.f, ln1 = 0.f, ln2 = 0.f, accum_depth_rec = 0.f, accum_alpha_rec = 0.f;
     float an0 = 0.f, an1 = 0.f, an2 = 0.f, last_dL_dT = 0.f, last_alpha = 0.f;
 
-    // Nothing behind the deepest contributor of the whole tile can receive a gradient: start there.
-    {
-        uint32_t m = last_contributor;
+    // nothing behind the deepest contributor of this quadrant can receive a gradient from it
+    uint32_t max_last = last_contributor;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
-        if (lane == 0) atomicMax(&s_max_last, m);
-    }
-    __syncthreads();
-    const uint32_t max_last = s_max_last;  // contributors are 1-based; splats with 0-based index >= max_last are dead
+    for (int d = 32; d >= 1; d >>= 1) max_last = max(max_last, (uint32_t)__shfl_xor((int)max_last, d, 64));
+    max_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_last);
 
-    // walk batches back to front; batch b covers 0-based splat indices [b*BATCH, b*BATCH+n)
-    const int nbatches = (int)((max_last + BWD_BATCH - 1) / BWD_BATCH);
+    const int ridx = reduce16_index(lane);
+    const bool writer = (lane & 3) == 0;
+    const int nbatches = (int)((max_last + 63) / 64);
     for (int b = nbatches - 1; b >= 0; b--) {
-        const uint32_t b0 = (uint32_t)b * BWD_BATCH;
-        const int n = (int)min((uint32_t)BWD_BATCH, max_last - b0);
-        __syncthreads();  // previous flush finished
-        for (int i = threadIdx.x; i < n * ACC_STRIDE; i += 256) acc[i] = 0.f;
-        if ((int)threadIdx.x < n) {
-            const uint32_t id = point_list[range.x + b0 + threadIdx.x];
-            sm_id[threadIdx.x] = id;
-            const float4* rp = rec + (size_t)id * GS2D_REC_F4;
-#pragma unroll
-            for (int k = 0; k < GS2D_REC_F4; k++) sm[k][threadIdx.x] = rp[k];
+        const uint32_t b0 = (uint32_t)b * 64;
+        const int n = (int)min(64u, max_last - b0);
+        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0, r4 = r0;
+        uint32_t my_id = 0;
+        bool touch = false;
+        if (lane < n) {
+            my_id = point_list[range.x + b0 + lane];
+            const float4* rp = rec + (size_t)my_id * GS2D_REC_F4;
+            r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4];
+            touch = splat_may_touch(r0, r1, r2, r4.z, fx0, fx1, fy0, fy1);
         }
-        __syncthreads();
-        for (int j = n - 1; j >= 0; j--) {
+        uint64_t mask = __ballot(touch);
+        while (mask) {
+            const int j = 63 - __builtin_clzll(mask);  // back to front
+            mask &= ~(1ull << j);
             const uint32_t contributor = b0 + (uint32_t)j;  // 0-based, as in backward.cu:285
             bool active = inside && contributor < last_contributor;
             if (__ballot(active) == 0) continue;
-            float g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, g_n0 = 0.f, g_n1 = 0.f, g_n2 = 0.f, g_op = 0.f;
-            float g_T0 = 0.f, g_T1 = 0.f, g_T2 = 0.f, g_T3 = 0.f, g_T4 = 0.f, g_T5 = 0.f, g_T6 = 0.f, g_T7 = 0.f, g_T8 = 0.f;
+            const float Tux = bcast(r0.x, j), Tuy = bcast(r0.y, j), Tuz = bcast(r0.z, j), cxy0 = bcast(r0.w, j);
+            const float Tvx = bcast(r1.x, j), Tvy = bcast(r1.y, j), Tvz = bcast(r1.z, j), cxy1 = bcast(r1.w, j);
+            const float Twx = bcast(r2.x, j), Twy = bcast(r2.y, j), Twz = bcast(r2.z, j), opa = bcast(r2.w, j);
+            float g[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) g[i] = 0.f;
             float g_mx = 0.f, g_my = 0.f;
             bool lowpass = false;
             if (active) {
-                const float4 q0 = sm[0][j], q1 = sm[1][j], q2 = sm[2][j];
-                const float k0 = pxf * q2.x - q0.x, k1 = pxf * q2.y - q0.y, k2 = pxf * q2.z - q0.z;
-                const float l0 = pyf * q2.x - q1.x, l1 = pyf * q2.y - q1.y, l2 = pyf * q2.z - q1.z;
-                const float p0 = k1 * l2 - k2 * l1;
-                const float p1 = k2 * l0 - k0 * l2;
-                const float p2 = k0 * l1 - k1 * l0;
+                const float k0 = fmaf(pxf, Twx, -Tux), k1 = fmaf(pxf, Twy, -Tuy), k2 = fmaf(pxf, Twz, -Tuz);
+                const float l0 = fmaf(pyf, Twx, -Tvx), l1 = fmaf(pyf, Twy, -Tvy), l2 = fmaf(pyf, Twz, -Tvz);
+                const float p0 = fmaf(k1, l2, -(k2 * l1));
+                const float p1 = fmaf(k2, l0, -(k0 * l2));
+                const float p2 = fmaf(k0, l1, -(k1 * l0));
                 active = !(p2 == 0.0f);
-                const float s0 = p0 / p2, s1 = p1 / p2;
-                const float rho3d = s0 * s0 + s1 * s1;
-                const float d0 = q0.w - pxf, d1 = q1.w - pyf;
-                const float rho2d = GS2D_FILTER_INV_SQ * (d0 * d0 + d1 * d1);
+                const float ip = fast_rcp(p2);
+                const float s0 = p0 * ip, s1 = p1 * ip;
+                const float rho3d = fmaf(s0, s0, s1 * s1);
+                const float d0 = cxy0 - pxf, d1 = cxy1 - pyf;
+                const float rho2d = GS2D_FILTER_INV_SQ * fmaf(d0, d0, d1 * d1);
                 const float rho = fminf(rho3d, rho2d);
-                float c_d = (rho3d <= rho2d) ? (s0 * q2.x + s1 * q2.y) + q2.z : q2.z;
+                float c_d = (rho3d <= rho2d) ? fmaf(s0, Twx, fmaf(s1, Twy, Twz)) : Twz;
                 active = active && !(c_d < GS2D_NEAR_N);
                 const float power = -0.5f * rho;
                 active = active && !(power > 0.0f);
-                const float G = expf(power);
-                const float alpha = fminf(0.99f, q2.w * G);
+                const float G = fast_exp(power);
+                const float alpha = fminf(0.99f, opa * G);
                 active = active && !(alpha < 1.0f / 255.0f);
                 if (active) {
-                    const float4 q3 = sm[3][j], q4 = sm[4][j];
-                    T = T / (1.f - alpha);
+                    const float nx = bcast(r3.x, j), ny = bcast(r3.y, j), nz = bcast(r3.z, j);
+                    const float cr = bcast(r3.w, j), cg = bcast(r4.x, j), cb = bcast(r4.y, j);
+                    const float ioma = fast_rcp(1.f - alpha);
+                    T = T * ioma;
                     const float w = alpha * T;
                     float dL_dalpha = 0.0f;
                     // backward.cu:331-344
-                    ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = q3.w;
-                    dL_dalpha += (q3.w - ar0) * dpx0; g_c0 = w * dpx0;
-                    ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = q4.x;
-                    dL_dalpha += (q4.x - ar1) * dpx1; g_c1 = w * dpx1;
-                    ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = q4.y;
-                    dL_dalpha += (q4.y - ar2) * dpx2; g_c2 = w * dpx2;
+                    ar0 = fmaf(last_alpha, lc0, (1.f - last_alpha) * ar0); lc0 = cr;
+                    dL_dalpha = fmaf(cr - ar0, dpx0, dL_dalpha); g[0] = w * dpx0;
+                    ar1 = fmaf(last_alpha, lc1, (1.f - last_alpha) * ar1); lc1 = cg;
+                    dL_dalpha = fmaf(cg - ar1, dpx1, dL_dalpha); g[1] = w * dpx1;
+                    ar2 = fmaf(last_alpha, lc2, (1.f - last_alpha) * ar2); lc2 = cb;
+                    dL_dalpha = fmaf(cb - ar2, dpx2, dL_dalpha); g[2] = w * dpx2;
                     float conf = 1.f;
-                    if (USE_SA) {  // backward.cu:347-351 (the reference evaluates this exp in double)
-                        conf = T < 0.5f ? expf(-(c_d - mm) * (c_d - mm) / (4 * fmaxf(mstd / (1 - T_final), 1e-7f))) : 1.f;
-                        c_d = c_d * conf + mm * (1 - conf);
+                    if (USE_SA) {  // backward.cu:347-351
+                        if (T < 0.5f) {
+                            const float dm = c_d - mm;
+                            conf = fast_exp(-(dm * dm) * sa_k);
+                        }
+                        c_d = fmaf(c_d, conf, mm * (1 - conf));
                     }
-                    float dL_dz = 0.0f, dL_dweight = 0.f;
-                    const float m_d = GS2D_FAR_N / (GS2D_FAR_N - GS2D_NEAR_N) * (1 - GS2D_NEAR_N / c_d);
-                    const float dmd_dd = (GS2D_FAR_N * GS2D_NEAR_N) / ((GS2D_FAR_N - GS2D_NEAR_N) * c_d * c_d);
-                    if (contributor == median_contributor - 1u) dL_dz += dL_dmedian_depth;
-                    if (USE_SA) dL_dweight += ((c_d - mm) * (c_d - mm)) * dL_dreg;
-                    else dL_dweight += (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
-                    dL_dalpha += dL_dweight - last_dL_dT;
-                    last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
-                    if (USE_SA) dL_dz += conf * 2.0f * w * (c_d - mm) * dL_dreg;
-                    else {
-                        const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
-                        dL_dz += dL_dmd * dmd_dd;
+                    float dL_dz = 0.0f, dL_dweight;
+                    if (contributor == median_contributor - 1u) dL_dz = dL_dmedian_depth;
+                    if (USE_SA) {
+                        const float dm = c_d - mm;
+                        dL_dweight = (dm * dm) * dL_dreg;
+                        dL_dalpha += dL_dweight - last_dL_dT;
+                        last_dL_dT = fmaf(dL_dweight, alpha, (1 - alpha) * last_dL_dT);
+                        dL_dz = fmaf(conf * 2.0f * w * dm, dL_dreg, dL_dz);
+                    } else {
+                        const float icd = fast_rcp(c_d);
+                        const float m_d = c1 * (1 - GS2D_NEAR_N * icd);
+                        const float dmd_dd = (c1 * GS2D_NEAR_N) * (icd * icd);
+                        dL_dweight = fmaf(m_d * m_d, final_A, fmaf(-2.0f * m_d, final_D, final_D2)) * dL_dreg;
+                        dL_dalpha += dL_dweight - last_dL_dT;
+                        last_dL_dT = fmaf(dL_dweight, alpha, (1 - alpha) * last_dL_dT);
+                        const float dL_dmd = 2.0f * w * fmaf(m_d, final_A, -final_D) * dL_dreg;
+                        dL_dz = fmaf(dL_dmd, dmd_dd, dL_dz);
                     }
-                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                    accum_depth_rec = fmaf(last_alpha, last_depth, (1.f - last_alpha) * accum_depth_rec);
                     last_depth = c_d;
-                    dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
-                    accum_alpha_rec = last_alpha + (1.f - last_alpha) * accum_alpha_rec;
-                    dL_dalpha += (1 - accum_alpha_rec) * dL_daccum;
+                    dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);
+                    accum_alpha_rec = fmaf(1.f - last_alpha, accum_alpha_rec, last_alpha);
+                    dL_dalpha = fmaf(1 - accum_alpha_rec, dL_daccum, dL_dalpha);
                     // backward.cu:392-397
-                    an0 = last_alpha * ln0 + (1.f - last_alpha) * an0; ln0 = q3.x;
-                    dL_dalpha += (q3.x - an0) * dn0; g_n0 = alpha * T * dn0;
-                    an1 = last_alpha * ln1 + (1.f - last_alpha) * an1; ln1 = q3.y;
-                    dL_dalpha += (q3.y - an1) * dn1; g_n1 = alpha * T * dn1;
-                    an2 = last_alpha * ln2 + (1.f - last_alpha) * an2; ln2 = q3.z;
-                    dL_dalpha += (q3.z - an2) * dn2; g_n2 = alpha * T * dn2;
+                    an0 = fmaf(last_alpha, ln0, (1.f - last_alpha) * an0); ln0 = nx;
+                    dL_dalpha = fmaf(nx - an0, dn0, dL_dalpha); g[3] = w * dn0;
+                    an1 = fmaf(last_alpha, ln1, (1.f - last_alpha) * an1); ln1 = ny;
+                    dL_dalpha = fmaf(ny - an1, dn1, dL_dalpha); g[4] = w * dn1;
+                    an2 = fmaf(last_alpha, ln2, (1.f - last_alpha) * an2); ln2 = nz;
+                    dL_dalpha = fmaf(nz - an2, dn2, dL_dalpha); g[5] = w * dn2;
                     dL_dalpha *= T;
                     last_alpha = alpha;
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-                    const float dL_dG = q2.w * dL_dalpha;
-                    dL_dz += conf * alpha * T * dL_ddepth;
+                    dL_dalpha = fmaf(-T_final * ioma, bg_dot, dL_dalpha);
+                    const float dL_dG = opa * dL_dalpha;
+                    dL_dz = fmaf(conf * w, dL_ddepth, dL_dz);
                     if (rho3d <= rho2d) {  // backward.cu:419-449
-                        const float dL_ds0 = dL_dG * -G * s0 + dL_dz * q2.x;
-                        const float dL_ds1 = dL_dG * -G * s1 + dL_dz * q2.y;
-                        const float dsx = dL_ds0 / p2, dsy = dL_ds1 / p2;
-                        const float dp0 = dsx, dp1 = dsy, dp2 = -(dsx * s0 + dsy * s1);
-                        const float dk0 = l1 * dp2 - l2 * dp1, dk1 = l2 * dp0 - l0 * dp2, dk2 = l0 * dp1 - l1 * dp0;
-                        const float dl0 = dp1 * k2 - dp2 * k1, dl1 = dp2 * k0 - dp0 * k2, dl2 = dp0 * k1 - dp1 * k0;
-                        g_T0 = -dk0; g_T1 = -dk1; g_T2 = -dk2;
-                        g_T3 = -dl0; g_T4 = -dl1; g_T5 = -dl2;
-                        g_T6 = pxf * dk0 + pyf * dl0 + dL_dz * s0;
-                        g_T7 = pxf * dk1 + pyf * dl1 + dL_dz * s1;
-                        g_T8 = pxf * dk2 + pyf * dl2 + dL_dz * 1.0f;
+                        const float gG = dL_dG * -G;
+                        const float dL_ds0 = fmaf(gG, s0, dL_dz * Twx);
+                        const float dL_ds1 = fmaf(gG, s1, dL_dz * Twy);
+                        const float dsx = dL_ds0 * ip, dsy = dL_ds1 * ip;
+                        const float dp2 = -fmaf(dsx, s0, dsy * s1);
+                        const float dk0 = fmaf(l1, dp2, -(l2 * dsy)), dk1 = fmaf(l2, dsx, -(l0 * dp2)), dk2 = fmaf(l0, dsy, -(l1 * dsx));
+                        const float dl0 = fmaf(dsy, k2, -(dp2 * k1)), dl1 = fmaf(dp2, k0, -(dsx * k2)), dl2 = fmaf(dsx, k1, -(dsy * k0));
+                        g[6] = -dk0; g[7] = -dk1; g[8] = -dk2;
+                        g[9] = -dl0; g[10] = -dl1; g[11] = -dl2;
+                        g[12] = fmaf(pxf, dk0, fmaf(pyf, dl0, dL_dz * s0));
+                        g[13] = fmaf(pxf, dk1, fmaf(pyf, dl1, dL_dz * s1));
+                        g[14] = fmaf(pxf, dk2, fmaf(pyf, dl2, dL_dz));
                     } else {  // backward.cu:450-457
-                        g_mx = dL_dG * (-G * GS2D_FILTER_INV_SQ * d0);
-                        g_my = dL_dG * (-G * GS2D_FILTER_INV_SQ * d1);
-                        g_T8 = dL_dz;
+                        const float t = dL_dG * (-G * GS2D_FILTER_INV_SQ);
+                        g_mx = t * d0;
+                        g_my = t * d1;
+                        g[14] = dL_dz;
                         lowpass = true;
                     }
-                    g_op = G * dL_dalpha;
+                    g[15] = G * dL_dalpha;
                 }
             }
             if (__ballot(active) == 0) continue;
-            // 64-lane sums (DPP), then lane 63 folds them into the tile accumulator in LDS
-            const bool any_lp = __ballot(lowpass) != 0;
-            g_c0 = wave_sum_to_lane63(g_c0); g_c1 = wave_sum_to_lane63(g_c1); g_c2 = wave_sum_to_lane63(g_c2);
-            g_n0 = wave_sum_to_lane63(g_n0); g_n1 = wave_sum_to_lane63(g_n1); g_n2 = wave_sum_to_lane63(g_n2);
-            g_T0 = wave_sum_to_lane63(g_T0); g_T1 = wave_sum_to_lane63(g_T1); g_T2 = wave_sum_to_lane63(g_T2);
-            g_T3 = wave_sum_to_lane63(g_T3); g_T4 = wave_sum_to_lane63(g_T4); g_T5 = wave_sum_to_lane63(g_T5);
-            g_T6 = wave_sum_to_lane63(g_T6); g_T7 = wave_sum_to_lane63(g_T7); g_T8 = wave_sum_to_lane63(g_T8);
-            g_op = wave_sum_to_lane63(g_op);
-            if (any_lp) { g_mx = wave_sum_to_lane63(g_mx); g_my = wave_sum_to_lane63(g_my); }
-            if (lane == 63) {
-                float* a = acc + j * ACC_STRIDE;
-                atomicAdd(a + 0, g_c0); atomicAdd(a + 1, g_c1); atomicAdd(a + 2, g_c2);
-                atomicAdd(a + 3, g_n0); atomicAdd(a + 4, g_n1); atomicAdd(a + 5, g_n2);
-                atomicAdd(a + 6, g_T0); atomicAdd(a + 7, g_T1); atomicAdd(a + 8, g_T2);
-                atomicAdd(a + 9, g_T3); atomicAdd(a + 10, g_T4); atomicAdd(a + 11, g_T5);
-                atomicAdd(a + 12, g_T6); atomicAdd(a + 13, g_T7); atomicAdd(a + 14, g_T8);
-                if (any_lp) { atomicAdd(a + 15, g_mx); atomicAdd(a + 16, g_my); }
-                atomicAdd(a + 17, g_op);
+            const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)my_id, j);
+            float* dst = grad_rec + (size_t)id * GS2D_GRAD_FLOATS;
+            const float tot = reduce16(g, lane);
+            if (writer) atomicAdd(dst + ridx, tot);
+            if (__ballot(lowpass) != 0) {
+                g_mx = wave_sum_to_lane63(g_mx);
+                g_my = wave_sum_to_lane63(g_my);
+                if (lane == 63) { atomicAdd(dst + 16, g_mx); atomicAdd(dst + 17, g_my); }
             }
-        }
-        __syncthreads();
-        // flush: 18 consecutive lanes add one splat's 72 contiguous bytes
-        for (int e = threadIdx.x; e < n * 18; e += 256) {
-            const int j = e / 18, k = e - j * 18;
-            const float v = acc[j * ACC_STRIDE + k];
-            if (v != 0.f) atomicAdd(grad_rec + (size_t)sm_id[j] * GS2D_GRAD_FLOATS + k, v);
         }
     }
 }

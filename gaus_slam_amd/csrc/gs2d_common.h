@@ -15,12 +15,13 @@
 // Splat record: 5 x float4 = 80 B per Gaussian, written once by the forward preprocess and
 // gathered by both blend kernels (one record = everything a pixel needs about a splat):
 //   q0 = (Tu.x, Tu.y, Tu.z, center.x)   q1 = (Tv.x, Tv.y, Tv.z, center.y)
-//   q2 = (Tw.x, Tw.y, Tw.z, opacity)    q3 = (n.x, n.y, n.z, red)   q4 = (green, blue, 0, 0)
+//   q2 = (Tw.x, Tw.y, Tw.z, opacity)    q3 = (n.x, n.y, n.z, red)   q4 = (green, blue, rho_max, 0)
+// rho_max = 2 ln(255 opacity) (+margin): cull bound only, see splat_may_touch() in gs2d_blend.hip.
 #define GS2D_REC_F4 5
 #define GS2D_REC_FLOATS 20
 
 // Gradient record accumulated by the backward blend, consumed by the backward preprocess:
-//   [0..2] dL_dcolor  [3..5] dL_dnormal  [6..14] dL_dT (Tu,Tv,Tw)  [15,16] dL_dmean2D.xy  [17] dL_dopacity
+//   [0..2] dL_dcolor  [3..5] dL_dnormal  [6..14] dL_dT (Tu,Tv,Tw)  [15] dL_dopacity  [16,17] dL_dmean2D.xy
 #define GS2D_GRAD_FLOATS 20
 
 // Pixel-state planes kept between forward and backward (element index = tile*256 + thread).

@@ -189,7 +189,11 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         r1 = make_float4(T[3], T[4], T[5], cy);
         r2 = make_float4(T[6], T[7], T[8], opacities[idx]);
         r3 = make_float4(normal[0], normal[1], normal[2], col[0]);
-        r4 = make_float4(col[1], col[2], 0.f, 0.f);
+        // q4.z: rho_max = 2 ln(255 opacity) with a safety margin -- the largest min(rho3d,rho2d) at which
+        // opacity*exp(-rho/2) can still reach 1/255.  Only used to CULL (never to decide) in the blend kernels.
+        const float opa = opacities[idx];
+        const float rho_max = opa > 0.f ? 2.0f * logf(255.0f * opa) * 1.0001f + 1e-3f : (opa == opa ? -1.f : 1e30f);
+        r4 = make_float4(col[1], col[2], rho_max, 0.f);
     } while (0);
     radii[idx] = out_radius;
     tiles_touched[idx] = out_tiles;
@@ -287,14 +291,14 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     float dcol[3] = {g[0], g[1], g[2]};
     dL_dcolor[3 * idx] = dcol[0]; dL_dcolor[3 * idx + 1] = dcol[1]; dL_dcolor[3 * idx + 2] = dcol[2];
     dL_dnormal[3 * idx] = g[3]; dL_dnormal[3 * idx + 1] = g[4]; dL_dnormal[3 * idx + 2] = g[5];
-    dL_dopacity[idx] = g[17];
+    dL_dopacity[idx] = g[15];
     float dT[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) dT[i] = g[6 + i];
     float dTout[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) dTout[i] = dT[i];  // what the reference leaves in dL_dtransMat
-    const float dmx = g[15], dmy = g[16];
+    const float dmx = g[16], dmy = g[17];
 
     const bool precomp = (scales == nullptr);
     const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];

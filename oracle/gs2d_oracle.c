@@ -20,6 +20,12 @@
  *     on the geometry that drives tile binning and the depth sort;
  *   - per-Gaussian gradient sums are accumulated in double (the reference
  *     uses float atomicAdd in a non-deterministic order);
+ *   - the per-(pixel,splat) arithmetic of the two blend stages is written in an explicit
+ *     fused-multiply-add form (fmaf) and with reciprocal-then-multiply instead of divisions.
+ *     nvcc contracts the reference's expressions into FMAs in a pattern of its own choosing
+ *     (--fmad=true default), so no particular contraction is "the" reference; this file fixes
+ *     one and the HIP kernels use exactly the same one, which leaves only the hardware
+ *     rcp/exp approximations (<= 1-2 ulp) between the two;
  *   - float->int conversions saturate and map NaN to 0 (CUDA cvt.rzi / AMD
  *     v_cvt semantics) instead of x86's INT_MIN.
  *
@@ -361,19 +367,20 @@ void orc_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_l
                     const float* Tm = transMats + 9 * (size_t)g;
                     const float Tu[3] = {Tm[0], Tm[1], Tm[2]}, Tv[3] = {Tm[3], Tm[4], Tm[5]},
                                 Tw[3] = {Tm[6], Tm[7], Tm[8]};
-                    /* forward.cu:360-371 */
-                    const float k[3] = {pxf * Tw[0] - Tu[0], pxf * Tw[1] - Tu[1], pxf * Tw[2] - Tu[2]};
-                    const float l[3] = {pyf * Tw[0] - Tv[0], pyf * Tw[1] - Tv[1], pyf * Tw[2] - Tv[2]};
-                    const float p0 = k[1] * l[2] - k[2] * l[1];
-                    const float p1 = k[2] * l[0] - k[0] * l[2];
-                    const float p2 = k[0] * l[1] - k[1] * l[0];
+                    /* forward.cu:360-371, in the FMA form shared with the HIP kernel (see header) */
+                    const float k[3] = {fmaf(pxf, Tw[0], -Tu[0]), fmaf(pxf, Tw[1], -Tu[1]), fmaf(pxf, Tw[2], -Tu[2])};
+                    const float l[3] = {fmaf(pyf, Tw[0], -Tv[0]), fmaf(pyf, Tw[1], -Tv[1]), fmaf(pyf, Tw[2], -Tv[2])};
+                    const float p0 = fmaf(k[1], l[2], -(k[2] * l[1]));
+                    const float p1 = fmaf(k[2], l[0], -(k[0] * l[2]));
+                    const float p2 = fmaf(k[0], l[1], -(k[1] * l[0]));
                     if (p2 == 0.0f) continue;
-                    const float s0 = p0 / p2, s1 = p1 / p2;
-                    const float rho3d = s0 * s0 + s1 * s1;
+                    const float ip = 1.0f / p2;
+                    const float s0 = p0 * ip, s1 = p1 * ip;
+                    const float rho3d = fmaf(s0, s0, s1 * s1);
                     const float d0 = means2D[2 * (size_t)g] - pxf, d1 = means2D[2 * (size_t)g + 1] - pyf;
-                    const float rho2d = FILTER_INV_SQ * (d0 * d0 + d1 * d1);
+                    const float rho2d = FILTER_INV_SQ * fmaf(d0, d0, d1 * d1);
                     const float rho = fmin_c(rho3d, rho2d);
-                    float depth = (rho3d <= rho2d) ? (s0 * Tw[0] + s1 * Tw[1]) + Tw[2] : Tw[2];
+                    float depth = (rho3d <= rho2d) ? fmaf(s0, Tw[0], fmaf(s1, Tw[1], Tw[2])) : Tw[2];
                     if (depth < NEAR_N) { if (stab) margin = fminf(margin, relm(depth, NEAR_N)); continue; }
                     const float* no = normal_opacity + 4 * (size_t)g;
                     const float power = -0.5f * rho;
@@ -395,31 +402,31 @@ void orc_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_l
                     if (use_sa) { /* forward.cu:405-416 */
                         if (Dp > 0) {
                             const float exp_depth = median_depth;
-                            float exp_std = (D2 - 2 * Dp * exp_depth) / (1 - T) + exp_depth * exp_depth;
+                            float exp_std = fmaf(fmaf(-2.0f * Dp, exp_depth, D2), 1.0f / (1 - T), exp_depth * exp_depth);
                             exp_std = fmax_c(exp_std, 1e-7f);
-                            const float error = (exp_depth - depth) * (exp_depth - depth);
-                            const float conf = expf(-error / (4 * exp_std));
-                            depth = conf * depth + (1 - conf) * exp_depth;
+                            const float e = exp_depth - depth;
+                            const float conf = expf(-(e * e) * (1.0f / (4 * exp_std)));
+                            depth = fmaf(conf, depth, (1 - conf) * exp_depth);
                         }
-                        Dp += depth * w;
-                        D2 += depth * depth * w;
+                        Dp = fmaf(depth, w, Dp);
+                        D2 = fmaf(depth * depth, w, D2);
                     } else { /* forward.cu:417-423 */
                         const float A = 1 - T;
-                        const float m = FAR_N / (FAR_N - NEAR_N) * (1 - NEAR_N / depth);
-                        distortion += (m * m * A + M2 - 2 * m * M1) * w;
-                        Dp += depth * w;
-                        M1 += m * w;
-                        M2 += m * m * w;
+                        const float m = (FAR_N / (FAR_N - NEAR_N)) * (1 - NEAR_N * (1.0f / depth));
+                        distortion = fmaf(fmaf(m * m, A, fmaf(-2.0f * m, M1, M2)), w, distortion);
+                        Dp = fmaf(depth, w, Dp);
+                        M1 = fmaf(m, w, M1);
+                        M2 = fmaf(m * m, w, M2);
                     }
-                    for (int ch = 0; ch < 3; ch++) N[ch] += no[ch] * w;
-                    for (int ch = 0; ch < 3; ch++) C[ch] += features[3 * (size_t)g + ch] * w;
+                    for (int ch = 0; ch < 3; ch++) N[ch] = fmaf(no[ch], w, N[ch]);
+                    for (int ch = 0; ch < 3; ch++) C[ch] = fmaf(features[3 * (size_t)g + ch], w, C[ch]);
                     T = test_T;
                     last_contributor = contributor;
                 }
                 /* forward.cu:441-466 */
                 final_T[pix] = T;
                 n_contrib[pix] = last_contributor;
-                for (int ch = 0; ch < 3; ch++) out_color[ch * HW + pix] = C[ch] + T * bg[ch];
+                for (int ch = 0; ch < 3; ch++) out_color[ch * HW + pix] = fmaf(T, bg[ch], C[ch]);
                 n_contrib[pix + HW] = median_contributor < 0 ? 0u : (uint32_t)median_contributor;
                 final_T[pix + HW] = M1;
                 final_T[pix + 2 * HW] = M2;
@@ -428,9 +435,9 @@ void orc_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_l
                 for (int ch = 0; ch < 3; ch++) out_others[pix + (2 + ch) * HW] = N[ch];
                 out_others[pix + 5 * HW] = median_depth;
                 median_depth_out[pix] = median_depth;
-                depth_std_out[pix] = D2 - 2 * median_depth * Dp + median_depth * median_depth * (1 - T);
-                out_others[pix + 6 * HW] =
-                    use_sa ? D2 - 2 * median_depth * Dp + (1 - T) * median_depth * median_depth : distortion;
+                const float dstd = fmaf(median_depth * median_depth, 1 - T, fmaf(-2.0f * median_depth, Dp, D2));
+                depth_std_out[pix] = dstd;
+                out_others[pix + 6 * HW] = use_sa ? dstd : distortion;
                 if (stab) stab[pix] = margin;
             }
     }
@@ -489,6 +496,10 @@ void orc_blend_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t* 
                 const float final_A = 1 - T_final;
                 float last_dL_dT = 0, last_alpha = 0, last_color[3] = {0, 0, 0};
                 for (int i = 0; i < 3; i++) dL_dpixel[i] = dL_dpixels[i * HW + pix];
+                const float bg_dot = fmaf(bg[2], dL_dpixel[2], fmaf(bg[1], dL_dpixel[1], bg[0] * dL_dpixel[0]));
+                /* backward.cu:349: 1 / (4 max(mstd/(1-T_final), 1e-7)) is a per-pixel constant */
+                const float sa_k = 1.0f / (4 * fmax_c(mstd * (1.0f / (1 - T_final)), 1e-7f));
+                const float c1 = FAR_N / (FAR_N - NEAR_N);
                 for (uint32_t it = r1; it-- > r0;) {
                     contributor--;
                     if (contributor >= last_contributor) continue;
@@ -496,18 +507,20 @@ void orc_blend_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t* 
                     const float* Tm = transMats + 9 * (size_t)g;
                     const float Tu[3] = {Tm[0], Tm[1], Tm[2]}, Tv[3] = {Tm[3], Tm[4], Tm[5]},
                                 Tw[3] = {Tm[6], Tm[7], Tm[8]};
-                    const float k[3] = {pxf * Tw[0] - Tu[0], pxf * Tw[1] - Tu[1], pxf * Tw[2] - Tu[2]};
-                    const float l[3] = {pyf * Tw[0] - Tv[0], pyf * Tw[1] - Tv[1], pyf * Tw[2] - Tv[2]};
-                    const float p0 = k[1] * l[2] - k[2] * l[1];
-                    const float p1 = k[2] * l[0] - k[0] * l[2];
-                    const float p2 = k[0] * l[1] - k[1] * l[0];
+                    /* same FMA form as the forward (and as the HIP kernel) */
+                    const float k[3] = {fmaf(pxf, Tw[0], -Tu[0]), fmaf(pxf, Tw[1], -Tu[1]), fmaf(pxf, Tw[2], -Tu[2])};
+                    const float l[3] = {fmaf(pyf, Tw[0], -Tv[0]), fmaf(pyf, Tw[1], -Tv[1]), fmaf(pyf, Tw[2], -Tv[2])};
+                    const float p0 = fmaf(k[1], l[2], -(k[2] * l[1]));
+                    const float p1 = fmaf(k[2], l[0], -(k[0] * l[2]));
+                    const float p2 = fmaf(k[0], l[1], -(k[1] * l[0]));
                     if (p2 == 0.0f) continue;
-                    const float s0 = p0 / p2, s1 = p1 / p2;
-                    const float rho3d = s0 * s0 + s1 * s1;
+                    const float ip = 1.0f / p2;
+                    const float s0 = p0 * ip, s1 = p1 * ip;
+                    const float rho3d = fmaf(s0, s0, s1 * s1);
                     const float d0 = means2D[2 * (size_t)g] - pxf, d1 = means2D[2 * (size_t)g + 1] - pyf;
-                    const float rho2d = FILTER_INV_SQ * (d0 * d0 + d1 * d1);
+                    const float rho2d = FILTER_INV_SQ * fmaf(d0, d0, d1 * d1);
                     const float rho = fmin_c(rho3d, rho2d);
-                    float c_d = (rho3d <= rho2d) ? (s0 * Tw[0] + s1 * Tw[1]) + Tw[2] : Tw[2];
+                    float c_d = (rho3d <= rho2d) ? fmaf(s0, Tw[0], fmaf(s1, Tw[1], Tw[2])) : Tw[2];
                     if (c_d < NEAR_N) continue;
                     const float* no = normal_opacity + 4 * (size_t)g;
                     const float power = -0.5f * rho;
@@ -515,75 +528,79 @@ void orc_blend_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t* 
                     const float G = expf(power);
                     const float alpha = fmin_c(0.99f, no[3] * G);
                     if (alpha < 1.0f / 255.0f) continue;
-                    T = T / (1.f - alpha);
+                    const float ioma = 1.0f / (1.f - alpha);
+                    T = T * ioma;
                     const float w = alpha * T;
                     float dL_dalpha = 0.0f;
                     for (int ch = 0; ch < 3; ch++) { /* backward.cu:331-344 */
                         const float c = colors[3 * (size_t)g + ch];
-                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                        accum_rec[ch] = fmaf(last_alpha, last_color[ch], (1.f - last_alpha) * accum_rec[ch]);
                         last_color[ch] = c;
-                        dL_dalpha += (c - accum_rec[ch]) * dL_dpixel[ch];
+                        dL_dalpha = fmaf(c - accum_rec[ch], dL_dpixel[ch], dL_dalpha);
                         acc_add(acc, g, ch, (double)(w * dL_dpixel[ch]));
                     }
                     float conf = 1;
-                    if (use_sa) { /* backward.cu:347-351; double exp as written in the reference */
+                    if (use_sa) { /* backward.cu:347-351 (float exp here; the reference promotes this one to double) */
                         if (T < 0.5f) {
-                            const double den = 4 * fmax((double)(mstd / (1 - T_final)), 1e-7);
-                            conf = (float)exp((double)(-(c_d - mm) * (c_d - mm)) / den);
-                        } else conf = 1.f;
-                        c_d = c_d * conf + mm * (1 - conf);
+                            const float dm = c_d - mm;
+                            conf = expf(-(dm * dm) * sa_k);
+                        }
+                        c_d = fmaf(c_d, conf, mm * (1 - conf));
                     }
-                    float dL_dz = 0.0f, dL_dweight = 0;
-                    const float m_d = FAR_N / (FAR_N - NEAR_N) * (1 - NEAR_N / c_d);
-                    const float dmd_dd = (FAR_N * NEAR_N) / ((FAR_N - NEAR_N) * c_d * c_d);
-                    if (contributor == median_contributor - 1u) dL_dz += dL_dmedian_depth;
-                    if (use_sa) dL_dweight += ((c_d - mm) * (c_d - mm)) * dL_dreg;
-                    else dL_dweight += (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
-                    dL_dalpha += dL_dweight - last_dL_dT;
-                    last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
-                    if (use_sa) dL_dz += conf * 2.0f * w * (c_d - mm) * dL_dreg;
-                    else {
-                        const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
-                        dL_dz += dL_dmd * dmd_dd;
+                    float dL_dz = 0.0f, dL_dweight;
+                    if (contributor == median_contributor - 1u) dL_dz = dL_dmedian_depth;
+                    if (use_sa) {
+                        const float dm = c_d - mm;
+                        dL_dweight = (dm * dm) * dL_dreg;
+                        dL_dalpha += dL_dweight - last_dL_dT;
+                        last_dL_dT = fmaf(dL_dweight, alpha, (1 - alpha) * last_dL_dT);
+                        dL_dz = fmaf(conf * 2.0f * w * dm, dL_dreg, dL_dz);
+                    } else {
+                        const float icd = 1.0f / c_d;
+                        const float m_d = c1 * (1 - NEAR_N * icd);
+                        const float dmd_dd = (c1 * NEAR_N) * (icd * icd);
+                        dL_dweight = fmaf(m_d * m_d, final_A, fmaf(-2.0f * m_d, final_D, final_D2)) * dL_dreg;
+                        dL_dalpha += dL_dweight - last_dL_dT;
+                        last_dL_dT = fmaf(dL_dweight, alpha, (1 - alpha) * last_dL_dT);
+                        const float dL_dmd = 2.0f * w * fmaf(m_d, final_A, -final_D) * dL_dreg;
+                        dL_dz = fmaf(dL_dmd, dmd_dd, dL_dz);
                     }
-                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                    accum_depth_rec = fmaf(last_alpha, last_depth, (1.f - last_alpha) * accum_depth_rec);
                     last_depth = c_d;
-                    dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
-                    accum_alpha_rec = last_alpha + (1.f - last_alpha) * accum_alpha_rec;
-                    dL_dalpha += (1 - accum_alpha_rec) * dL_daccum;
+                    dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);
+                    accum_alpha_rec = fmaf(1.f - last_alpha, accum_alpha_rec, last_alpha);
+                    dL_dalpha = fmaf(1 - accum_alpha_rec, dL_daccum, dL_dalpha);
                     for (int ch = 0; ch < 3; ch++) { /* backward.cu:392-397 */
-                        accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
+                        accum_normal_rec[ch] = fmaf(last_alpha, last_normal[ch], (1.f - last_alpha) * accum_normal_rec[ch]);
                         last_normal[ch] = no[ch];
-                        dL_dalpha += (no[ch] - accum_normal_rec[ch]) * dL_dnormal2D[ch];
-                        acc_add(acc, g, 3 + ch, (double)(alpha * T * dL_dnormal2D[ch]));
+                        dL_dalpha = fmaf(no[ch] - accum_normal_rec[ch], dL_dnormal2D[ch], dL_dalpha);
+                        acc_add(acc, g, 3 + ch, (double)(w * dL_dnormal2D[ch]));
                     }
                     dL_dalpha *= T;
                     last_alpha = alpha;
-                    float bg_dot = 0;
-                    for (int i = 0; i < 3; i++) bg_dot += bg[i] * dL_dpixel[i];
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                    dL_dalpha = fmaf(-T_final * ioma, bg_dot, dL_dalpha);
                     const float dL_dG = no[3] * dL_dalpha;
-                    dL_dz += conf * alpha * T * dL_ddepth;
+                    dL_dz = fmaf(conf * w, dL_ddepth, dL_dz);
                     if (rho3d <= rho2d) { /* backward.cu:419-449 */
-                        const float dL_ds0 = dL_dG * -G * s0 + dL_dz * Tw[0];
-                        const float dL_ds1 = dL_dG * -G * s1 + dL_dz * Tw[1];
-                        const float dsx = dL_ds0 / p2, dsy = dL_ds1 / p2;
-                        const float dp[3] = {dsx, dsy, -(dsx * s0 + dsy * s1)};
-                        const float dk[3] = {l[1] * dp[2] - l[2] * dp[1], l[2] * dp[0] - l[0] * dp[2],
-                                             l[0] * dp[1] - l[1] * dp[0]};
-                        const float dl[3] = {dp[1] * k[2] - dp[2] * k[1], dp[2] * k[0] - dp[0] * k[2],
-                                             dp[0] * k[1] - dp[1] * k[0]};
-                        const float dz_dTw[3] = {s0, s1, 1.0f};
+                        const float gG = dL_dG * -G;
+                        const float dL_ds0 = fmaf(gG, s0, dL_dz * Tw[0]);
+                        const float dL_ds1 = fmaf(gG, s1, dL_dz * Tw[1]);
+                        const float dsx = dL_ds0 * ip, dsy = dL_ds1 * ip;
+                        const float dp2 = -fmaf(dsx, s0, dsy * s1);
+                        const float dk[3] = {fmaf(l[1], dp2, -(l[2] * dsy)), fmaf(l[2], dsx, -(l[0] * dp2)),
+                                             fmaf(l[0], dsy, -(l[1] * dsx))};
+                        const float dl[3] = {fmaf(dsy, k[2], -(dp2 * k[1])), fmaf(dp2, k[0], -(dsx * k[2])),
+                                             fmaf(dsx, k[1], -(dsy * k[0]))};
+                        const float dz_dTw[3] = {dL_dz * s0, dL_dz * s1, dL_dz};
                         for (int i = 0; i < 3; i++) {
                             acc_add(acc, g, 6 + i, (double)(-dk[i]));
                             acc_add(acc, g, 9 + i, (double)(-dl[i]));
-                            acc_add(acc, g, 12 + i, (double)(pxf * dk[i] + pyf * dl[i] + dL_dz * dz_dTw[i]));
+                            acc_add(acc, g, 12 + i, (double)fmaf(pxf, dk[i], fmaf(pyf, dl[i], dz_dTw[i])));
                         }
                     } else { /* backward.cu:450-457 */
-                        const float dG_ddelx = -G * FILTER_INV_SQ * d0;
-                        const float dG_ddely = -G * FILTER_INV_SQ * d1;
-                        acc_add(acc, g, 15, (double)(dL_dG * dG_ddelx));
-                        acc_add(acc, g, 16, (double)(dL_dG * dG_ddely));
+                        const float t = dL_dG * (-G * FILTER_INV_SQ);
+                        acc_add(acc, g, 15, (double)(t * d0));
+                        acc_add(acc, g, 16, (double)(t * d1));
                         acc_add(acc, g, 14, (double)dL_dz);
                     }
                     acc_add(acc, g, 17, (double)(G * dL_dalpha));
