@@ -1,0 +1,82 @@
+"""N>1 path on CPU: world_size-2 gloo processes run the keyframe-sharded BA step (gaus_slam_amd/ba_shard.py) with
+a stand-in differentiable render function; the all-reduced bucket must equal the serial sum over keyframes, and
+world_size 1 must reproduce the local gradients bit for bit."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gaus_slam_amd import ba_shard
+
+
+def _params(P, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return {name: torch.randn(P, k, generator=g).requires_grad_(True) for name, k in ba_shard.BUCKET_FIELDS.items()}
+
+
+def _fake_render_loss(params, kf):
+    """Any differentiable function of all five parameter groups that depends on the keyframe."""
+    a = float(kf + 1)
+    return ((params["means3D"] * a).sin().sum() + (params["opacities"] * a).sum() ** 2 * 1e-3 +
+            (params["scales"] ** 2).sum() * a + (params["rotations"] * params["rotations"].roll(1, 1)).sum() * a +
+            (params["colors"] * (a + params["means3D"])).sum())
+
+
+def _serial(P, keyframes):
+    out = None
+    for kf in keyframes:
+        p = _params(P)
+        _fake_render_loss(p, kf).backward()
+        flat = torch.cat([p[n].grad.reshape(-1) for n in ba_shard.BUCKET_FIELDS])
+        out = flat if out is None else out + flat
+    return out
+
+
+def _worker(rank, world, port, P, keyframes, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ba = ba_shard.KeyframeShardedBA(_params(P), _fake_render_loss)
+        ba.step(keyframes)
+        if rank == 0:
+            q.put(ba.bucket.flat.clone())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("keyframes", [[0, 1], [0, 1, 2], [5]])
+def test_world2_equals_serial_sum(keyframes):
+    P, world, port = 257, 2, 29513 + len(keyframes)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, P, keyframes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.testing.assert_close(got, _serial(P, keyframes), rtol=1e-5, atol=1e-5)
+
+
+def test_world1_is_bitwise_local():
+    P = 100
+    ba = ba_shard.KeyframeShardedBA(_params(P), _fake_render_loss)
+    views = ba.step([3])
+    p = _params(P)
+    _fake_render_loss(p, 3).backward()
+    for n in ba_shard.BUCKET_FIELDS:
+        assert torch.equal(views[n], p[n].grad)
+    assert ba.bucket.flat.numel() == 13 * P
+
+
+def test_bucket_layout_and_sharding():
+    b = ba_shard.GradBucket(10, "cpu")
+    assert [tuple(v.shape) for v in b.views.values()] == [(10, 3), (10, 1), (10, 2), (10, 4), (10, 3)]
+    assert all(v.is_contiguous() for v in b.views.values()) and ba_shard.BUCKET_FLOATS == 13
+    assert ba_shard.shard_keyframes(list(range(5)), 1, 2) == [1, 3]
+    b.pack({"means3D": torch.ones(10, 3)})
+    assert b.flat[:30].sum() == 30 and b.flat[30:].abs().sum() == 0

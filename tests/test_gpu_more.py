@@ -1,0 +1,207 @@
+"""More GPU parity tests (through the C ABI / operator mirror): committed golden vectors incl. the SH and
+precomputed-transMat paths, edge cases, BASELINE.json's full bench size, a culling stress scene, simple_knn,
+mark_visible and the autograd operator surface."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+IMG_TOL, GRAD_TOL, KNIFE = 1e-4, 1e-4, 2e-5
+
+
+def _scene_from_golden(d):
+    from gaus_slam_amd.scene_synth import Camera
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    cam = Camera(W=int(d["W"]), H=int(d["H"]), tanfovx=float(d["tanfovx"]), tanfovy=float(d["tanfovy"]),
+                 viewmatrix=t(d["viewmatrix"]), projmatrix=t(d["projmatrix"]), campos=t(d["campos"]), K=None, w2c=None)
+    return dict(means3D=t(d["means3D"]), scales=t(d["scales"]), rotations=t(d["rotations"]), opacities=t(d["opacities"]),
+                colors=t(d["colors"]), cam=cam)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_golden_vectors(path):
+    d = np.load(path)
+    sc = _scene_from_golden(d)
+    kind = str(d["kind"])
+    kw = {}
+    if kind == "sh3":
+        kw.update(shs=d["shs"], sh_degree=3)
+    if kind == "precomp":
+        kw.update(transMat_precomp=d["transMat_precomp"])
+    h = util.hip_forward(sc, use_sa=bool(d["use_sa"]), bg=d["bg"], **kw)
+    assert h["num_rendered"] == int(d["num_rendered"])
+    np.testing.assert_array_equal(h["radii"], d["radii"])
+    np.testing.assert_array_equal(h["point_list"], d["point_list"])
+    np.testing.assert_array_equal(h["ranges"], d["ranges"])
+    H, W = int(d["H"]), int(d["W"])
+    assert d["stability"].min() > KNIFE  # the fixtures contain no knife-edge pixel: compare everything
+    np.testing.assert_array_equal(h["last_contributor"].reshape(-1), d["n_contrib"][:H * W])
+    np.testing.assert_array_equal(h["median_contributor"].reshape(-1), d["n_contrib"][H * W:])
+    assert np.abs(h["color"] - d["color"]).max() <= IMG_TOL
+    assert np.abs(h["allmap"] - d["allmap"]).max() <= IMG_TOL
+    g = util.hip_backward(h, d["dL_dcolor"], d["dL_dallmap"])
+    keys = ["dL_dcolors", "dL_dopacity", "dL_dtransMat", "dL_dmeans2D"]
+    keys += ["dL_dmeans3D"] if kind != "precomp" or True else []
+    if kind != "precomp":
+        keys += ["dL_dscales", "dL_drotations"]
+    if kind == "sh3":
+        keys += ["dL_dsh"]
+    for k in keys:
+        assert util.grad_err(g[k], d[k].reshape(g[k].shape)) <= GRAD_TOL, k
+
+
+def test_empty_and_fully_culled(oracle):
+    from gaus_slam_amd import rasterizer
+    dev = torch.device("cuda")
+    e = torch.empty(0, device=dev)
+    sc = util.make_scene(64, 64, 48, seed=1, regime="tracking")
+    cam = sc["cam"]
+    z3, z1 = torch.zeros(0, 3, device=dev), torch.zeros(0, 1, device=dev)
+    R, color, allmap, radii, *_ = rasterizer.rasterize_gaussians(
+        torch.tensor([0.1, 0.2, 0.3], device=dev), z3, z3, z1, torch.zeros(0, 2, device=dev), torch.zeros(0, 4, device=dev),
+        1.0, e, cam.viewmatrix.to(dev), cam.projmatrix.to(dev), cam.tanfovx, cam.tanfovy, 48, 64, e, 0,
+        cam.campos.to(dev), True, False, False)
+    assert R == 0 and radii.numel() == 0 and float(color.abs().max()) == 0 and float(allmap.abs().max()) == 0  # rasterize_points.cu:100
+    # every Gaussian behind the camera: R = 0, image = background
+    sc["means3D"][:, 2] = -sc["means3D"][:, 2].abs() - 1.0
+    bg = (0.1, 0.2, 0.3)
+    h = util.hip_forward(sc, bg=bg)
+    o = util.oracle_forward(oracle, sc, bg=bg)
+    assert h["num_rendered"] == 0 == o["num_rendered"] and (h["radii"] == 0).all()
+    np.testing.assert_allclose(h["color"], o["color"])
+    np.testing.assert_allclose(h["color"][:, 5, 7], bg)
+    g = util.hip_backward(h, np.ones((3, 48, 64), np.float32), np.ones((7, 48, 64), np.float32))
+    assert all(np.abs(v).max() == 0 for v in g.values() if v.size)
+
+
+def test_debug_flag_and_scale_modifier(oracle):
+    sc = util.make_scene(500, 96, 80, seed=5, regime="mapping")
+    o = util.oracle_forward(oracle, sc, scale_modifier=1.7)
+    h = util.hip_forward(sc, scale_modifier=1.7, debug=True)
+    np.testing.assert_array_equal(h["point_list"], o["point_list"])
+    stable = (o["stability"] > KNIFE).reshape(80, 96)
+    assert np.abs(h["allmap"] - o["allmap"])[:, stable].max() <= IMG_TOL
+
+
+def test_culling_stress_extreme_splats(oracle):
+    """Grazing, huge, tiny, near-plane and behind-the-eye-crossing surfels: the quadrant cull must never drop a
+    contributing pair (bit-exact n_contrib / images vs the oracle, which has no culling)."""
+    P, W, H = 3000, 208, 160
+    sc = util.make_scene(P, W, H, seed=21, regime="mapping", max_tilt_deg=89.9, scale_lo=0.05, scale_hi=60.0)
+    rng = np.random.default_rng(3)
+    sc["means3D"][: P // 10, 2] = torch.from_numpy(rng.uniform(0.2, 0.35, P // 10).astype(np.float32))  # hugging the near plane
+    sc["opacities"][P // 10: P // 5] = 1.0  # opacity above the 0.99 alpha clamp
+    sc["opacities"][P // 5: P // 4] = 0.004  # around the 1/255 visibility threshold
+    sc["scales"][P // 4: P // 3] *= 30.0  # discs that cross the eye plane
+    o = util.oracle_forward(oracle, sc, use_sa=True)
+    h = util.hip_forward(sc, use_sa=True)
+    np.testing.assert_array_equal(h["point_list"], o["point_list"])
+    stable = (o["stability"] > KNIFE).reshape(H, W)
+    assert (~stable).mean() < 0.01
+    np.testing.assert_array_equal(h["last_contributor"][stable], o["n_contrib"][:H * W].reshape(H, W)[stable])
+    assert np.abs(h["color"] - o["color"])[:, stable].max() <= IMG_TOL
+    # depth-like channels scale with the (unbounded) depths of this scene: compare relative to magnitude
+    for c in range(7):
+        scale = max(1.0, float(np.abs(o["allmap"][c]).max()))
+        assert np.abs(h["allmap"][c] - o["allmap"][c])[stable].max() <= IMG_TOL * scale, c
+    dc, da = util.make_upstream_grads(W, H, channels=(0, 1, 2, 3, 4, 5, 6))
+    dc, da = (dc * W * H).numpy(), (da * W * H).numpy()
+    dc[:, ~stable] = 0; da[:, ~stable] = 0
+    go = oracle.backward(o, dc, da)
+    gh = util.hip_backward(h, dc, da)
+    for k in ["dL_dcolors", "dL_dopacity", "dL_dtransMat", "dL_dmeans3D", "dL_dscales", "dL_drotations"]:
+        assert util.grad_err(gh[k], go[k].reshape(gh[k].shape)) <= 5e-4, k
+
+
+@pytest.mark.parametrize("regime", ["mapping"])
+def test_full_bench_size_500k(oracle, regime):
+    """BASELINE.json metric size: 640x480, 500k Gaussians, checked against the oracle (multi-threaded) plus
+    size-independent properties."""
+    P, W, H = 500000, 640, 480
+    sc = util.make_scene(P, W, H, seed=0, regime=regime)
+    oracle.set_threads(os.cpu_count() or 1)
+    o = util.oracle_forward(oracle, sc, use_sa=True)
+    h = util.hip_forward(sc, use_sa=True)
+    assert h["num_rendered"] == o["num_rendered"]
+    np.testing.assert_array_equal(h["radii"], o["radii"])
+    np.testing.assert_array_equal(h["point_list"], o["point_list"])
+    np.testing.assert_array_equal(h["ranges"], o["ranges"])
+    # properties: keys sorted, ranges partition [0,R), alpha in [0,1)
+    mask = np.uint64((1 << o["nbits"]) - 1)
+    k = h["keys"] & mask
+    assert (k[1:] >= k[:-1]).all()
+    lens = h["ranges"][:, 1].astype(np.int64) - h["ranges"][:, 0]
+    assert lens.sum() == h["num_rendered"]
+    assert (h["allmap"][1] >= 0).all() and (h["allmap"][1] < 1).all()
+    stable = (o["stability"] > KNIFE).reshape(H, W)
+    assert (~stable).mean() < 5e-3
+    HW = H * W
+    np.testing.assert_array_equal(h["last_contributor"][stable], o["n_contrib"][:HW].reshape(H, W)[stable])
+    assert np.abs(h["color"] - o["color"])[:, stable].max() <= IMG_TOL
+    assert np.abs(h["allmap"] - o["allmap"])[:, stable].max() <= IMG_TOL
+    dc, da = util.make_upstream_grads(W, H)
+    dc, da = (dc * W * H).numpy(), (da * W * H).numpy()
+    dc[:, ~stable] = 0; da[:, ~stable] = 0
+    go = oracle.backward(o, dc, da)
+    gh = util.hip_backward(h, dc, da)
+    for k in ["dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dtransMat"]:
+        assert util.grad_err(gh[k], go[k].reshape(gh[k].shape)) <= GRAD_TOL, k
+    oracle.set_threads(1)
+
+
+def test_mark_visible(oracle):
+    from gaus_slam_amd import rasterizer
+    sc = util.make_scene(5000, 320, 240, seed=2, regime="mapping")
+    cam = sc["cam"]
+    dev = torch.device("cuda")
+    got = rasterizer.mark_visible(sc["means3D"].to(dev), cam.viewmatrix.to(dev), cam.projmatrix.to(dev)).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.mark_visible(sc["means3D"].numpy(), cam.viewmatrix.numpy()))
+    assert 0 < got.sum() < 5000
+
+
+@pytest.mark.parametrize("N", [1, 3, 5, 1000, 40000])
+def test_simple_knn_dist2(oracle, N):
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(N)
+    pts = rng.normal(size=(N, 3)).astype(np.float32)
+    if N >= 1000:
+        pts[: N // 10] = pts[N // 10: 2 * (N // 10)]  # exact duplicates
+    got = distCUDA2(torch.from_numpy(pts).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.dist2_knn3(pts))  # exact k-NN set, same expression order: bit-exact
+
+
+def test_autograd_operator_surface(oracle):
+    """Drive the op the way render/render_2dgs.py + slam/Loss.py do: settings NamedTuple, GaussianRasterizer module,
+    means2D grad sink, weight-normalised depth, masked L1 loss; gradients vs the oracle fed with the same upstream
+    gradients."""
+    from gaus_slam_amd import render as gsr
+    W, H, P = 160, 120, 2000
+    sc = util.make_scene(P, W, H, seed=9, regime="tracking")
+    dev = torch.device("cuda")
+    params = {k: sc[k].to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "colors")}
+    means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+    settings = gsr.settings_from_camera(sc["cam"], dev, use_sa=True)
+    pkg = gsr.render(settings, params["means3D"], means2D, params["opacities"], colors_precomp=params["colors"],
+                     scales=params["scales"], rotations=params["rotations"], use_weight_norm=True)
+    for t in (pkg["render_color"], pkg["allmap"]):
+        t.retain_grad()
+    target_c = torch.full((3, H, W), 0.4, device=dev)
+    target_d = torch.full((1, H, W), 2.5, device=dev)
+    mask = (pkg["render_alpha"] > 0.5).float()
+    loss = ((pkg["render_color"] - target_c).abs() * mask).sum() + ((pkg["render_depth"] - target_d).abs() * mask).sum() \
+        + 0.1 * pkg["render_dist"].mean()
+    loss.backward()
+    assert pkg["radius"].dtype == torch.int32 and not pkg["radius"].requires_grad
+    o = util.oracle_forward(oracle, sc, use_sa=True)
+    go = oracle.backward(o, pkg["render_color"].grad.cpu().numpy(), pkg["allmap"].grad.cpu().numpy())
+    for name, k in (("means3D", "dL_dmeans3D"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"),
+                    ("opacities", "dL_dopacity"), ("colors", "dL_dcolors")):
+        assert util.grad_err(params[name].grad.cpu().numpy(), go[k].reshape(params[name].shape)) <= 2e-4, name
+    assert util.grad_err(means2D.grad.cpu().numpy(), go["dL_dmeans2D"]) <= 2e-4
+    assert float(means2D.grad[:, 2].abs().max()) == 0
