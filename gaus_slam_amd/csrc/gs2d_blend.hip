@@ -4,9 +4,10 @@
 // Design (gfx950, wave64):
 //   * one workgroup per 16x16 tile, 4 waves, each wave owns an 8x8 pixel quadrant (compact footprint ->
 //     coherent per-wave skip / early-out decisions);
-//   * the tile's depth-sorted splat list is consumed in batches of 64: each lane keeps one packed 80-byte
-//     splat record in registers, a conservative cull test per quadrant is ballot-ed into a 64-bit mask, and the
-//     wave walks the set bits broadcasting the record with v_readlane (no LDS, no barrier in the loops);
+//   * the tile's depth-sorted splat list is consumed in batches of 64: each lane fetches one packed 80-byte
+//     splat record, a conservative cull test per quadrant is ballot-ed into a 64-bit mask, the records are staged
+//     in wave-private LDS and the wave walks the set bits reading them back as broadcasts, prefetched one ahead
+//     (no workgroup barrier anywhere in the loops);
 //   * forward: the 4 waves run independently (no workgroup barrier in the loop; a wave leaves as soon as
 //     its 64 pixels are saturated);
 //   * backward: per-(pixel,splat) gradients are summed over the 64 lanes with a 16-value permlane/DPP butterfly
@@ -17,14 +18,6 @@
 #include "gs2d_common.h"
 
 namespace {
-
-__device__ __forceinline__ void wave_lds_fence()
-{
-    // LDS operations of one wave execute in order; this only stops the compiler from reordering them.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // ------------------------------------------------------------------------------------------- helpers
 __device__ __forceinline__ float bcast(float v, int lane)  // wave-uniform broadcast of lane `lane` (v_readlane_b32)
@@ -64,19 +57,59 @@ __device__ __forceinline__ bool splat_may_touch(const float4 q0, const float4 q1
     return !(bx1 < x0 || bx0 > x1 || by1 < y0 || by0 > y1);
 }
 
+// Part A of the per-(pixel, splat) work: ray-splat intersection and alpha (forward.cu:360-387; FMA form identical
+// to oracle/gs2d_oracle.c).  Branch-free; `ok` folds the reference's skip tests in their original order
+// (p.z == 0, depth < near, power > 0, alpha < 1/255).
+__device__ __forceinline__ void fwd_eval(const float4 q0, const float4 q1, const float4 q2, float pxf, float pyf,
+                                         float& alpha, float& depth, bool& ok)
+{
+    const float k0 = fmaf(pxf, q2.x, -q0.x), k1 = fmaf(pxf, q2.y, -q0.y), k2 = fmaf(pxf, q2.z, -q0.z);
+    const float l0 = fmaf(pyf, q2.x, -q1.x), l1 = fmaf(pyf, q2.y, -q1.y), l2 = fmaf(pyf, q2.z, -q1.z);
+    const float p0 = fmaf(k1, l2, -(k2 * l1));
+    const float p1 = fmaf(k2, l0, -(k0 * l2));
+    const float p2 = fmaf(k0, l1, -(k1 * l0));
+    const float ip = fast_rcp(p2);
+    const float s0 = p0 * ip, s1 = p1 * ip;
+    const float rho3d = fmaf(s0, s0, s1 * s1);
+    const float d0 = q0.w - pxf, d1 = q1.w - pyf;
+    const float rho2d = GS2D_FILTER_INV_SQ * fmaf(d0, d0, d1 * d1);
+    const float rho = fminf(rho3d, rho2d);
+    depth = (rho3d <= rho2d) ? fmaf(s0, q2.x, fmaf(s1, q2.y, q2.z)) : q2.z;
+    const float power = -0.5f * rho;
+    alpha = fminf(0.99f, q2.w * fast_exp(power));
+    ok = !(p2 == 0.0f) && !(depth < GS2D_NEAR_N) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+}
+
+// Wave-private LDS staging of one 64-splat batch: lane i writes record i, any lane reads record j as a
+// same-address broadcast (conflict-free).  LDS operations of one wave execute in order; the fence only stops
+// the compiler from reordering them.
+struct WaveBatch {
+    float4 q[GS2D_REC_F4][64];
+};
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ------------------------------------------------------------------------------------------- forward
-// One wave per 8x8 pixel quadrant, 4 independent waves per 16x16 tile.  Each lane keeps ONE splat record of the
-// current 64-splat batch in registers; the wave walks the set bits of the cull mask and broadcasts the record of
-// splat j with v_readlane (SGPR operands): no LDS, no barrier, no memory latency inside the per-splat loop.
+// One wave per 8x8 pixel quadrant, 4 independent waves per 16x16 tile.  Each lane fetches ONE splat record of the
+// current 64-splat batch, tests it against the quadrant, and stages it in wave-private LDS; the wave then walks
+// the set bits of the cull mask reading record j back as a same-address broadcast (5 x ds_read_b128, software-
+// pipelined one splat ahead).  The VALU only does per-pixel math: v_readlane broadcasts cost ~6 SIMD cycles each
+// on gfx950 and drag v_movs behind them (one-SGPR-per-VALU-op limit); LDS broadcasts cost the VALU nothing.
 template <bool USE_SA>
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
                  float* __restrict__ out_others, float* __restrict__ pix_state, size_t plane)
 {
+    __shared__ WaveBatch batches[4];
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    WaveBatch& wb = batches[wave];
     const int qx0 = tx * GS2D_TILE + (wave & 1) * 8, qy0 = ty * GS2D_TILE + (wave >> 1) * 8;
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < W && py < H;
@@ -94,45 +127,37 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     for (uint32_t base = range.x; base < range.y; base += 64) {
         if (__ballot(!done) == 0) break;
         const int n = min(64, (int)(range.y - base));
-        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0, r4 = r0;
         bool touch = false;
+        wave_lds_sync();  // previous batch fully consumed before it is overwritten
         if (lane < n) {
             const uint32_t id = point_list[base + lane];
             const float4* rp = rec + (size_t)id * GS2D_REC_F4;
-            r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4];
+            const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4];
             touch = splat_may_touch(r0, r1, r2, r4.z, fx0, fx1, fy0, fy1);
+            wb.q[0][lane] = r0; wb.q[1][lane] = r1; wb.q[2][lane] = r2; wb.q[3][lane] = r3; wb.q[4][lane] = r4;
         }
+        wave_lds_sync();
         uint64_t mask = __ballot(touch);
-        while (mask) {
-            if (__ballot(!done) == 0) break;
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const float Tux = bcast(r0.x, j), Tuy = bcast(r0.y, j), Tuz = bcast(r0.z, j), cxy0 = bcast(r0.w, j);
-            const float Tvx = bcast(r1.x, j), Tvy = bcast(r1.y, j), Tvz = bcast(r1.z, j), cxy1 = bcast(r1.w, j);
-            const float Twx = bcast(r2.x, j), Twy = bcast(r2.y, j), Twz = bcast(r2.z, j), opa = bcast(r2.w, j);
-            if (!done) {
+        if (mask == 0) continue;
+        // software pipeline: the record of the NEXT surviving splat is fetched from LDS while the current one is
+        // evaluated, so the ds_read latency never sits on the critical path.
+        int j = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        float4 c0 = wb.q[0][j], c1 = wb.q[1][j], c2 = wb.q[2][j], c3 = wb.q[3][j], c4 = wb.q[4][j];
+        for (;;) {
+            const bool more = mask != 0;
+            const int jn = more ? __builtin_ctzll(mask) : j;
+            mask &= mask - 1;  // no-op when mask == 0
+            const float4 n0 = wb.q[0][jn], n1 = wb.q[1][jn], n2 = wb.q[2][jn], n3 = wb.q[3][jn], n4 = wb.q[4][jn];
+            float alpha, depth;
+            bool ok;
+            fwd_eval(c0, c1, c2, pxf, pyf, alpha, depth, ok);
+            const float test_T = T * (1 - alpha);
+            const bool pass = ok && !done;
+            const bool stop = pass && test_T < 0.0001f;
+            done = done || stop;
+            if (pass && !stop) {
                 const uint32_t contributor = (base - range.x) + (uint32_t)j + 1u;
-                // forward.cu:360-371 (FMA form, identical to oracle/gs2d_oracle.c)
-                const float k0 = fmaf(pxf, Twx, -Tux), k1 = fmaf(pxf, Twy, -Tuy), k2 = fmaf(pxf, Twz, -Tuz);
-                const float l0 = fmaf(pyf, Twx, -Tvx), l1 = fmaf(pyf, Twy, -Tvy), l2 = fmaf(pyf, Twz, -Tvz);
-                const float p0 = fmaf(k1, l2, -(k2 * l1));
-                const float p1 = fmaf(k2, l0, -(k0 * l2));
-                const float p2 = fmaf(k0, l1, -(k1 * l0));
-                if (p2 == 0.0f) continue;
-                const float ip = fast_rcp(p2);
-                const float s0 = p0 * ip, s1 = p1 * ip;
-                const float rho3d = fmaf(s0, s0, s1 * s1);
-                const float d0 = cxy0 - pxf, d1 = cxy1 - pyf;
-                const float rho2d = GS2D_FILTER_INV_SQ * fmaf(d0, d0, d1 * d1);
-                const float rho = fminf(rho3d, rho2d);
-                float depth = (rho3d <= rho2d) ? fmaf(s0, Twx, fmaf(s1, Twy, Twz)) : Twz;
-                if (depth < GS2D_NEAR_N) continue;
-                const float power = -0.5f * rho;
-                if (power > 0.0f) continue;
-                const float alpha = fminf(0.99f, opa * fast_exp(power));
-                if (alpha < 1.0f / 255.0f) continue;
-                const float test_T = T * (1 - alpha);
-                if (test_T < 0.0001f) { done = true; continue; }
                 const float w = alpha * T;
                 if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }
                 if (USE_SA) {  // forward.cu:405-416
@@ -154,11 +179,14 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                     M1 = fmaf(m, w, M1);
                     M2 = fmaf(m * m, w, M2);
                 }
-                N0 = fmaf(bcast(r3.x, j), w, N0); N1 = fmaf(bcast(r3.y, j), w, N1); N2 = fmaf(bcast(r3.z, j), w, N2);
-                C0 = fmaf(bcast(r3.w, j), w, C0); C1 = fmaf(bcast(r4.x, j), w, C1); C2 = fmaf(bcast(r4.y, j), w, C2);
+                N0 = fmaf(c3.x, w, N0); N1 = fmaf(c3.y, w, N1); N2 = fmaf(c3.z, w, N2);
+                C0 = fmaf(c3.w, w, C0); C1 = fmaf(c4.x, w, C1); C2 = fmaf(c4.y, w, C2);
                 T = test_T;
                 last_contributor = contributor;
             }
+            if (!more || __ballot(!done) == 0) break;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4;
+            j = jn;
         }
     }
     if (inside) {  // forward.cu:441-466
@@ -253,7 +281,7 @@ __device__ __forceinline__ int reduce16_index(int lane)
 // Gradient record (GS2D_GRAD_FLOATS = 20 floats per Gaussian):
 //   [0..2] dL_dcolor  [3..5] dL_dnormal  [6..14] dL_dT (Tu,Tv,Tw)  [15] dL_dopacity  [16,17] dL_dmean2D.xy
 //
-// One wave per 8x8 quadrant, waves independent (no LDS, no barrier).  Per contributing (wave, splat) pair the 16
+// One wave per 8x8 quadrant, waves independent (wave-private LDS staging, no workgroup barrier).  Per contributing (wave, splat) pair the 16
 // main components are reduced with the butterfly above and added with ONE global atomic instruction whose 16
 // active lanes cover 64 contiguous bytes of the Gaussian's record (the reference issues 16-18 atomics per
 // (pixel, splat) pair).
@@ -264,9 +292,11 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                  size_t plane, const float* __restrict__ dL_dpix, const float* __restrict__ dL_dothers,
                  float* __restrict__ grad_rec)
 {
+    __shared__ WaveBatch batches[4];
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    WaveBatch& wb = batches[wave];
     const int qx0 = tx * GS2D_TILE + (wave & 1) * 8, qy0 = ty * GS2D_TILE + (wave >> 1) * 8;
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < W && py < H;
@@ -299,7 +329,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const float final_A = 1 - T_final;
     const float bg_dot = fmaf(bg[2], dpx2, fmaf(bg[1], dpx1, bg[0] * dpx0));
     const float sa_k = 1.0f / (4 * fmaxf(mstd * (1.0f / (1 - T_final)), 1e-7f));  // per-pixel constant (IEEE, as the oracle)
-    const float c1 = GS2D_FAR_N / (GS2D_FAR_N - GS2D_NEAR_N);
+    const float c1f = GS2D_FAR_N / (GS2D_FAR_N - GS2D_NEAR_N);
     float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
     float last_depth = 0.f, ln0 = 0.f, ln1 = 0.f, ln2 = 0.f, accum_depth_rec = 0.f, accum_alpha_rec = 0.f;
     float an0 = 0.f, an1 = 0.f, an2 = 0.f, last_dL_dT = 0.f, last_alpha = 0.f;
@@ -316,64 +346,66 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     for (int b = nbatches - 1; b >= 0; b--) {
         const uint32_t b0 = (uint32_t)b * 64;
         const int n = (int)min(64u, max_last - b0);
-        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0, r4 = r0;
-        uint32_t my_id = 0;
         bool touch = false;
+        wave_lds_sync();  // previous batch fully consumed before it is overwritten
         if (lane < n) {
-            my_id = point_list[range.x + b0 + lane];
+            const uint32_t my_id = point_list[range.x + b0 + lane];
             const float4* rp = rec + (size_t)my_id * GS2D_REC_F4;
-            r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4];
+            const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+            float4 r4 = rp[4];
             touch = splat_may_touch(r0, r1, r2, r4.z, fx0, fx1, fy0, fy1);
+            r4.w = __uint_as_float(my_id);  // the Gaussian id rides in the unused slot of the staged record
+            wb.q[0][lane] = r0; wb.q[1][lane] = r1; wb.q[2][lane] = r2; wb.q[3][lane] = r3; wb.q[4][lane] = r4;
         }
+        wave_lds_sync();
         uint64_t mask = __ballot(touch);
-        while (mask) {
-            const int j = 63 - __builtin_clzll(mask);  // back to front
-            mask &= ~(1ull << j);
+        if (mask == 0) continue;
+        // back to front; geometry of the next surviving splat is prefetched from LDS during the current one
+        int j = 63 - __builtin_clzll(mask);
+        mask &= ~(1ull << j);
+        float4 c0 = wb.q[0][j], c1 = wb.q[1][j], c2 = wb.q[2][j];
+        for (;;) {
+            const bool more = mask != 0;
+            const int jn = more ? 63 - __builtin_clzll(mask) : j;
+            mask &= ~(1ull << jn);
+            const float4 n0 = wb.q[0][jn], n1 = wb.q[1][jn], n2 = wb.q[2][jn];
+            const float4 c3 = wb.q[3][j], c4 = wb.q[4][j];
             const uint32_t contributor = b0 + (uint32_t)j;  // 0-based, as in backward.cu:285
             bool active = inside && contributor < last_contributor;
-            if (__ballot(active) == 0) continue;
-            const float Tux = bcast(r0.x, j), Tuy = bcast(r0.y, j), Tuz = bcast(r0.z, j), cxy0 = bcast(r0.w, j);
-            const float Tvx = bcast(r1.x, j), Tvy = bcast(r1.y, j), Tvz = bcast(r1.z, j), cxy1 = bcast(r1.w, j);
-            const float Twx = bcast(r2.x, j), Twy = bcast(r2.y, j), Twz = bcast(r2.z, j), opa = bcast(r2.w, j);
-            float g[16];
+            if (__ballot(active) != 0) {
+                float g[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++) g[i] = 0.f;
-            float g_mx = 0.f, g_my = 0.f;
-            bool lowpass = false;
-            if (active) {
-                const float k0 = fmaf(pxf, Twx, -Tux), k1 = fmaf(pxf, Twy, -Tuy), k2 = fmaf(pxf, Twz, -Tuz);
-                const float l0 = fmaf(pyf, Twx, -Tvx), l1 = fmaf(pyf, Twy, -Tvy), l2 = fmaf(pyf, Twz, -Tvz);
+                for (int i = 0; i < 16; i++) g[i] = 0.f;
+                float g_mx = 0.f, g_my = 0.f;
+                bool lowpass = false;
+                const float k0 = fmaf(pxf, c2.x, -c0.x), k1 = fmaf(pxf, c2.y, -c0.y), k2 = fmaf(pxf, c2.z, -c0.z);
+                const float l0 = fmaf(pyf, c2.x, -c1.x), l1 = fmaf(pyf, c2.y, -c1.y), l2 = fmaf(pyf, c2.z, -c1.z);
                 const float p0 = fmaf(k1, l2, -(k2 * l1));
                 const float p1 = fmaf(k2, l0, -(k0 * l2));
                 const float p2 = fmaf(k0, l1, -(k1 * l0));
-                active = !(p2 == 0.0f);
                 const float ip = fast_rcp(p2);
                 const float s0 = p0 * ip, s1 = p1 * ip;
                 const float rho3d = fmaf(s0, s0, s1 * s1);
-                const float d0 = cxy0 - pxf, d1 = cxy1 - pyf;
+                const float d0 = c0.w - pxf, d1 = c1.w - pyf;
                 const float rho2d = GS2D_FILTER_INV_SQ * fmaf(d0, d0, d1 * d1);
                 const float rho = fminf(rho3d, rho2d);
-                float c_d = (rho3d <= rho2d) ? fmaf(s0, Twx, fmaf(s1, Twy, Twz)) : Twz;
-                active = active && !(c_d < GS2D_NEAR_N);
+                float c_d = (rho3d <= rho2d) ? fmaf(s0, c2.x, fmaf(s1, c2.y, c2.z)) : c2.z;
                 const float power = -0.5f * rho;
-                active = active && !(power > 0.0f);
                 const float G = fast_exp(power);
-                const float alpha = fminf(0.99f, opa * G);
-                active = active && !(alpha < 1.0f / 255.0f);
+                const float alpha = fminf(0.99f, c2.w * G);
+                active = active && !(p2 == 0.0f) && !(c_d < GS2D_NEAR_N) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                 if (active) {
-                    const float nx = bcast(r3.x, j), ny = bcast(r3.y, j), nz = bcast(r3.z, j);
-                    const float cr = bcast(r3.w, j), cg = bcast(r4.x, j), cb = bcast(r4.y, j);
                     const float ioma = fast_rcp(1.f - alpha);
                     T = T * ioma;
                     const float w = alpha * T;
                     float dL_dalpha = 0.0f;
                     // backward.cu:331-344
-                    ar0 = fmaf(last_alpha, lc0, (1.f - last_alpha) * ar0); lc0 = cr;
-                    dL_dalpha = fmaf(cr - ar0, dpx0, dL_dalpha); g[0] = w * dpx0;
-                    ar1 = fmaf(last_alpha, lc1, (1.f - last_alpha) * ar1); lc1 = cg;
-                    dL_dalpha = fmaf(cg - ar1, dpx1, dL_dalpha); g[1] = w * dpx1;
-                    ar2 = fmaf(last_alpha, lc2, (1.f - last_alpha) * ar2); lc2 = cb;
-                    dL_dalpha = fmaf(cb - ar2, dpx2, dL_dalpha); g[2] = w * dpx2;
+                    ar0 = fmaf(last_alpha, lc0, (1.f - last_alpha) * ar0); lc0 = c3.w;
+                    dL_dalpha = fmaf(c3.w - ar0, dpx0, dL_dalpha); g[0] = w * dpx0;
+                    ar1 = fmaf(last_alpha, lc1, (1.f - last_alpha) * ar1); lc1 = c4.x;
+                    dL_dalpha = fmaf(c4.x - ar1, dpx1, dL_dalpha); g[1] = w * dpx1;
+                    ar2 = fmaf(last_alpha, lc2, (1.f - last_alpha) * ar2); lc2 = c4.y;
+                    dL_dalpha = fmaf(c4.y - ar2, dpx2, dL_dalpha); g[2] = w * dpx2;
                     float conf = 1.f;
                     if (USE_SA) {  // backward.cu:347-351
                         if (T < 0.5f) {
@@ -392,8 +424,8 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                         dL_dz = fmaf(conf * 2.0f * w * dm, dL_dreg, dL_dz);
                     } else {
                         const float icd = fast_rcp(c_d);
-                        const float m_d = c1 * (1 - GS2D_NEAR_N * icd);
-                        const float dmd_dd = (c1 * GS2D_NEAR_N) * (icd * icd);
+                        const float m_d = c1f * (1 - GS2D_NEAR_N * icd);
+                        const float dmd_dd = (c1f * GS2D_NEAR_N) * (icd * icd);
                         dL_dweight = fmaf(m_d * m_d, final_A, fmaf(-2.0f * m_d, final_D, final_D2)) * dL_dreg;
                         dL_dalpha += dL_dweight - last_dL_dT;
                         last_dL_dT = fmaf(dL_dweight, alpha, (1 - alpha) * last_dL_dT);
@@ -406,21 +438,21 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                     accum_alpha_rec = fmaf(1.f - last_alpha, accum_alpha_rec, last_alpha);
                     dL_dalpha = fmaf(1 - accum_alpha_rec, dL_daccum, dL_dalpha);
                     // backward.cu:392-397
-                    an0 = fmaf(last_alpha, ln0, (1.f - last_alpha) * an0); ln0 = nx;
-                    dL_dalpha = fmaf(nx - an0, dn0, dL_dalpha); g[3] = w * dn0;
-                    an1 = fmaf(last_alpha, ln1, (1.f - last_alpha) * an1); ln1 = ny;
-                    dL_dalpha = fmaf(ny - an1, dn1, dL_dalpha); g[4] = w * dn1;
-                    an2 = fmaf(last_alpha, ln2, (1.f - last_alpha) * an2); ln2 = nz;
-                    dL_dalpha = fmaf(nz - an2, dn2, dL_dalpha); g[5] = w * dn2;
+                    an0 = fmaf(last_alpha, ln0, (1.f - last_alpha) * an0); ln0 = c3.x;
+                    dL_dalpha = fmaf(c3.x - an0, dn0, dL_dalpha); g[3] = w * dn0;
+                    an1 = fmaf(last_alpha, ln1, (1.f - last_alpha) * an1); ln1 = c3.y;
+                    dL_dalpha = fmaf(c3.y - an1, dn1, dL_dalpha); g[4] = w * dn1;
+                    an2 = fmaf(last_alpha, ln2, (1.f - last_alpha) * an2); ln2 = c3.z;
+                    dL_dalpha = fmaf(c3.z - an2, dn2, dL_dalpha); g[5] = w * dn2;
                     dL_dalpha *= T;
                     last_alpha = alpha;
                     dL_dalpha = fmaf(-T_final * ioma, bg_dot, dL_dalpha);
-                    const float dL_dG = opa * dL_dalpha;
+                    const float dL_dG = c2.w * dL_dalpha;
                     dL_dz = fmaf(conf * w, dL_ddepth, dL_dz);
                     if (rho3d <= rho2d) {  // backward.cu:419-449
                         const float gG = dL_dG * -G;
-                        const float dL_ds0 = fmaf(gG, s0, dL_dz * Twx);
-                        const float dL_ds1 = fmaf(gG, s1, dL_dz * Twy);
+                        const float dL_ds0 = fmaf(gG, s0, dL_dz * c2.x);
+                        const float dL_ds1 = fmaf(gG, s1, dL_dz * c2.y);
                         const float dsx = dL_ds0 * ip, dsy = dL_ds1 * ip;
                         const float dp2 = -fmaf(dsx, s0, dsy * s1);
                         const float dk0 = fmaf(l1, dp2, -(l2 * dsy)), dk1 = fmaf(l2, dsx, -(l0 * dp2)), dk2 = fmaf(l0, dsy, -(l1 * dsx));
@@ -439,17 +471,20 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                     }
                     g[15] = G * dL_dalpha;
                 }
+                if (__ballot(active) != 0) {
+                    float* dst = grad_rec + (size_t)__float_as_uint(c4.w) * GS2D_GRAD_FLOATS;
+                    const float tot = reduce16(g, lane);
+                    if (writer) atomicAdd(dst + ridx, tot);
+                    if (__ballot(lowpass) != 0) {
+                        g_mx = wave_sum_to_lane63(g_mx);
+                        g_my = wave_sum_to_lane63(g_my);
+                        if (lane == 63) { atomicAdd(dst + 16, g_mx); atomicAdd(dst + 17, g_my); }
+                    }
+                }
             }
-            if (__ballot(active) == 0) continue;
-            const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)my_id, j);
-            float* dst = grad_rec + (size_t)id * GS2D_GRAD_FLOATS;
-            const float tot = reduce16(g, lane);
-            if (writer) atomicAdd(dst + ridx, tot);
-            if (__ballot(lowpass) != 0) {
-                g_mx = wave_sum_to_lane63(g_mx);
-                g_my = wave_sum_to_lane63(g_my);
-                if (lane == 63) { atomicAdd(dst + 16, g_mx); atomicAdd(dst + 17, g_my); }
-            }
+            if (!more) break;
+            c0 = n0; c1 = n1; c2 = n2;
+            j = jn;
         }
     }
 }
