@@ -88,6 +88,11 @@ class KeyframeShardedBA:
         """One BA step over a batch of keyframes (len == world_size in the bench; ragged batches allowed: ranks
         without a keyframe contribute zeros).  Returns the reduced bucket views (name -> [P,k])."""
         mine = shard_keyframes(keyframes, self.rank, self.world_size)
+        if self.world_size == 1 and len(mine) == 1:
+            # degenerate K=1 case == the single-GPU path, bit for bit: no bucket, no copies, no collective
+            g = self.local_backward(mine[0])
+            return OrderedDict((name, g[name].reshape(v.shape) if g.get(name) is not None else torch.zeros_like(v))
+                               for name, v in self.bucket.views.items())
         if not mine:
             self.bucket.flat.zero_()
         else:

@@ -211,6 +211,7 @@ __device__ void sh_backward(int idx, int deg, int M, const float* means, const f
     const float x = ox / len, y = oy / len, z = oz / len;
     const float* sh = shs + (size_t)idx * M * 3;
     float* dsh = dL_dshs + (size_t)idx * M * 3;
+    for (int i = 3 * (deg + 1) * (deg + 1); i < 3 * M; i++) dsh[i] = 0.f;  // coefficients above the active degree
     float dRGB[3];
     for (int c = 0; c < 3; c++) dRGB[c] = dL_dcolor[c] * (clamped[3 * idx + c] ? 0.f : 1.f);
     float ddir[3] = {0, 0, 0};
@@ -279,7 +280,22 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       float* __restrict__ dL_dmean3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P || !(radii[idx] > 0)) return;
+    if (idx >= P) return;
+    if (!(radii[idx] > 0)) {
+        // culled in the forward: every gradient is exactly zero (the reference gets this from torch::zeros,
+        // rasterize_points.cu:192-200; here the kernel writes it so the caller can hand in uninitialised memory)
+#pragma unroll
+        for (int i = 0; i < 3; i++) { dL_dcolor[3 * idx + i] = 0.f; dL_dnormal[3 * idx + i] = 0.f; dL_dmean2D[3 * idx + i] = 0.f; dL_dmean3D[3 * idx + i] = 0.f; }
+        dL_dopacity[idx] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; i++) dL_dtransMat[9 * (size_t)idx + i] = 0.f;
+        dL_dscale[2 * idx] = 0.f; dL_dscale[2 * idx + 1] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) dL_drot[4 * idx + i] = 0.f;
+        if (shs != nullptr)
+            for (int i = 0; i < 3 * M; i++) dL_dsh[(size_t)idx * M * 3 + i] = 0.f;
+        return;
+    }
     const float4* gr4 = reinterpret_cast<const float4*>(grad_rec) + (size_t)idx * (GS2D_GRAD_FLOATS / 4);
     float g[GS2D_GRAD_FLOATS];
 #pragma unroll
@@ -384,13 +400,20 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         sh_backward(idx, D, M, means3D, cam.campos, shs, clamped, dcol, dmean, dL_dsh);
         have_mean = true;
     }
-    if (have_mean) { dL_dmean3D[3 * idx] = dmean[0]; dL_dmean3D[3 * idx + 1] = dmean[1]; dL_dmean3D[3 * idx + 2] = dmean[2]; }
+    (void)have_mean;
+    dL_dmean3D[3 * idx] = dmean[0]; dL_dmean3D[3 * idx + 1] = dmean[1]; dL_dmean3D[3 * idx + 2] = dmean[2];
+    if (precomp || early) {  // no scale / rotation gradient on these paths (backward.cu:565-579)
+        dL_dscale[2 * idx] = 0.f; dL_dscale[2 * idx + 1] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) dL_drot[4 * idx + i] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 9; i++) dL_dtransMat[9 * (size_t)idx + i] = dTout[i];
     // densification hack, backward.cu:660-663 (double arithmetic as written in the reference)
     const float depth = q2.z;
     dL_dmean2D[3 * idx + 0] = (float)((double)(dTout[2] * depth) * 0.5 * (double)(float)cam.W);
     dL_dmean2D[3 * idx + 1] = (float)((double)(dTout[5] * depth) * 0.5 * (double)(float)cam.H);
+    dL_dmean2D[3 * idx + 2] = 0.f;
 }
 
 // rasterizer_impl.cu:54-66

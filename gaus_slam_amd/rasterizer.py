@@ -67,9 +67,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     L = _lib.lib()
     dev = means3D.device
     P, H, W = means3D.size(0), int(image_height), int(image_width)
-    out_color = torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
-    out_others = torch.zeros((7, H, W), dtype=torch.float32, device=dev)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    # P == 0 returns zero images (rasterize_points.cu:100-101); otherwise the kernels write every output element,
+    # so no fill kernels are spent on them.
+    alloc = torch.zeros if P == 0 else torch.empty
+    out_color = alloc((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    out_others = alloc((7, H, W), dtype=torch.float32, device=dev)
+    radii = alloc((P,), dtype=torch.int32, device=dev)
     geom, binning, img = _Chunk(dev), _Chunk(dev), _Chunk(dev)
     rendered = 0
     if P != 0:
@@ -105,7 +108,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.size(0) != 0 else 0
-    z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+    # the backward kernels write every element (zeros for culled Gaussians): no torch.zeros fills needed
+    z = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dnormal = z(P, 3), z(P, 3), z(P, NUM_CHANNELS), z(P, 3)
     dL_dopacity, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations = z(P, 1), z(P, 9), z(P, M, 3), z(P, 2), z(P, 4)
     if P != 0:

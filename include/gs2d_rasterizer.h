@@ -73,7 +73,8 @@ int gs2d_forward(
     int* radii,                       /* [P] */
     int use_sa, int debug, void* stream);
 
-/* All dL_* outputs must be zero-initialised by the caller (rasterize_points.cu:192-200). */
+/* Every element of every dL_* output is written (zeros for Gaussians culled by the forward), so the caller may
+ * pass uninitialised memory; the reference relies on torch::zeros instead (rasterize_points.cu:192-200). */
 int gs2d_backward(
     int P, int D, int M, int R,
     const float* background,

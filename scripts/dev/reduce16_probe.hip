@@ -1,17 +1,26 @@
 // Probe: which of the 16 reduced values does each lane hold after reduce16()?
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-__device__ __forceinline__ float swapadd32(float a, float b)  // lanes 0-31: a[l]+a[l+32]; lanes 32-63: b[l-32]+b[l]
+// v_permlane32_swap / v_permlane16_swap via inline asm: the ROCm 7.2 builtins drop their second result
+// (scripts/dev/swap_probe.hip).  hipcc inserts no wait states around asm statements, so each level issues all of
+// its (independent) swaps inside ONE asm block with the hazard nops at the block boundaries only.
+__device__ __forceinline__ void swap32_x8(float v[16])  // pairs (v[2i], v[2i+1]): v[2i].hi <-> v[2i+1].lo
 {
-    // v_permlane32_swap: a.hi <-> b.lo.  Inline asm because the ROCm 7.2 builtin drops its second result
-    // (scripts/dev/swap_probe.hip); hipcc adds no wait states around asm, so the nops live in the string.
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    return a + b;
+    asm("s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\t"
+        "v_permlane32_swap_b32 %6, %7\n\tv_permlane32_swap_b32 %8, %9\n\tv_permlane32_swap_b32 %10, %11\n\t"
+        "v_permlane32_swap_b32 %12, %13\n\tv_permlane32_swap_b32 %14, %15\n\t"
+        "s_nop 1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+          "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
 }
-__device__ __forceinline__ float swapadd16(float a, float b)  // even rows: a (row r + row r+1); odd rows: b
+__device__ __forceinline__ void swap16_x4(float c[8])  // pairs (c[2i], c[2i+1]): odd rows of c[2i] <-> even rows of c[2i+1]
 {
-    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    return a + b;
+    asm("s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+        "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
+        "s_nop 1"
+        : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
 }
 template <int CTRL> __device__ __forceinline__ float dpp_get(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
@@ -20,16 +29,23 @@ template <int CTRL> __device__ __forceinline__ float seladd(float a, float b, bo
     const float keep = hi ? b : a, give = hi ? a : b;
     return keep + dpp_get<CTRL>(give);
 }
-__device__ __forceinline__ float reduce16(const float v[16], int lane) {
-    float c[8], d[4], e[2];
-    for (int i = 0; i < 8; i++) c[i] = swapadd32(v[2 * i], v[2 * i + 1]);
-    for (int i = 0; i < 4; i++) d[i] = swapadd16(c[2 * i], c[2 * i + 1]);
+__device__ __forceinline__ float reduce16(const float vin[16], int lane)
+{
+    float v[16], c[8], d[4], e[2];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = vin[i];
+    swap32_x8(v);  // lanes 0-31 now hold both halves of v[2i], lanes 32-63 both halves of v[2i+1]
+#pragma unroll
+    for (int i = 0; i < 8; i++) c[i] = v[2 * i] + v[2 * i + 1];
+    swap16_x4(c);
+#pragma unroll
+    for (int i = 0; i < 4; i++) d[i] = c[2 * i] + c[2 * i + 1];
     const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
-    e[0] = seladd<0x140>(d[0], d[1], b3);
+    e[0] = seladd<0x140>(d[0], d[1], b3);  // row_mirror: l <-> 15-l flips bit 3
     e[1] = seladd<0x140>(d[2], d[3], b3);
-    float f = seladd<0x141>(e[0], e[1], b2);
-    f += dpp_get<0x4E>(f);
-    f += dpp_get<0xB1>(f);
+    float f = seladd<0x141>(e[0], e[1], b2);  // row_half_mirror: l <-> 7-l flips bit 2
+    f += dpp_get<0x4E>(f);                    // quad_perm [2,3,0,1]
+    f += dpp_get<0xB1>(f);                    // quad_perm [1,0,3,2]
     return f;
 }
 __global__ void probe(float* out) {
