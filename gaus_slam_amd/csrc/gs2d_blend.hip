@@ -27,20 +27,26 @@ __device__ __forceinline__ float bcast(float v, int lane)  // wave-uniform broad
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }          // v_rcp_f32, 1 ulp
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }  // v_exp_f32
 
-// Conservative screen-space bound of the pixels a splat can touch with alpha >= 1/255, evaluated by the lane
-// that holds the splat record.  rho_max = 2 ln(255 opacity) (+margin, precomputed by the preprocess kernel):
-//   alpha >= 1/255  <=>  min(rho3d, rho2d) <= rho_max
-// {rho3d <= rho_max} is the projection of the disc u^2+v^2 <= rho_max of the surfel; when that disc lies
-// safely in front of the eye its image is an ellipse whose exact AABB follows from the same closed form the
-// reference uses for its 3-sigma box (forward.cu:119-147) with cutoff^2 = rho_max; {rho2d <= rho_max} is a
-// disc of radius sqrt(rho_max/100) px around the stored centre.  Anything that cannot be bounded safely is kept.
-// Returns true when the splat may touch the pixel rectangle [x0,x1] x [y0,y1].
+// Conservative test "can this splat reach alpha >= 1/255 on any pixel of the rectangle [x0,x1] x [y0,y1]?",
+// evaluated by the lane that holds the splat record.  rho_max = 2 ln(255 opacity) (+margin, precomputed by the
+// preprocess kernel):   alpha >= 1/255  <=>  min(rho3d, rho2d) <= rho_max.
+//  (1) {rho2d <= rho_max} is a disc of radius sqrt(rho_max/100) px around the stored centre.
+//  (2) {rho3d <= rho_max} is the image of the disc u^2+v^2 <= rho_max of the surfel.  When that disc lies safely
+//      in front of the eye the image is an ellipse; its exact AABB follows from the closed form the reference uses
+//      for its 3-sigma box (forward.cu:119-147) with cutoff^2 = rho_max.
+//  (3) Inside the AABB the ellipse itself is tested: with k = x Tw - Tu, l = y Tw - Tv the kernel's p = k x l is
+//      LINEAR in the pixel, p = A dx + B dy + C (A = Tw x l, B = k x Tw, C = k x l at the rectangle centre), so
+//      F = p.x^2 + p.y^2 - rho_max p.z^2 is an exact quadratic whose sign is the sign of rho3d - rho_max.  For a
+//      convex F the minimum over the rectangle lies at the ellipse centre (if inside) or on one of the 4 edges,
+//      where F is a 1-D parabola.  The splat is dropped only if that minimum exceeds a rounding margin.
+// Anything that cannot be bounded safely is kept.  Culling therefore never changes a result: a culled pair is one
+// the reference would have `continue`d past (tests: bit-exact n_contrib on a stress scene).
 __device__ __forceinline__ bool splat_may_touch(const float4 q0, const float4 q1, const float4 q2, float rho_max,
                                                 float x0, float x1, float y0, float y1)
 {
-    if (!(rho_max >= 0.f)) return false;  // opacity*G can never reach 1/255 (rho_max < 0; NaN opacity is encoded as +huge)
+    if (!(rho_max >= 0.f)) return false;  // opacity*G can never reach 1/255 (NaN opacity is encoded as +huge)
     const float rl = sqrtf(rho_max * (1.0f / GS2D_FILTER_INV_SQ)) + 0.5f;
-    float bx0 = q0.w - rl, bx1 = q0.w + rl, by0 = q1.w - rl, by1 = q1.w + rl;
+    const bool lowpass_near = !(q0.w + rl < x0 || q0.w - rl > x1 || q1.w + rl < y0 || q1.w - rl > y1);
     const float a = rho_max * (q2.x * q2.x + q2.y * q2.y), zz = q2.z * q2.z;
     if (!(a <= 0.9f * zz) || !(q2.z > 0.f)) return true;  // disc not safely in front of the eye: no bound
     const float inv = 1.0f / (a - zz);
@@ -52,9 +58,41 @@ __device__ __forceinline__ bool splat_may_touch(const float4 q0, const float4 q1
     if (!(hx == hx) || !(hy == hy)) return true;
     const float ex = sqrtf(fmaxf(hx, 0.f)), ey = sqrtf(fmaxf(hy, 0.f));
     const float mx = 0.5f + 0.02f * ex + 1e-4f * fabsf(cx), my = 0.5f + 0.02f * ey + 1e-4f * fabsf(cy);
-    bx0 = fminf(bx0, cx - ex - mx); bx1 = fmaxf(bx1, cx + ex + mx);
-    by0 = fminf(by0, cy - ey - my); by1 = fmaxf(by1, cy + ey + my);
-    return !(bx1 < x0 || bx0 > x1 || by1 < y0 || by0 > y1);
+    if (cx + ex + mx < x0 || cx - ex - mx > x1 || cy + ey + my < y0 || cy - ey - my > y1) return lowpass_near;
+    if (lowpass_near) return true;
+    // ellipse centre inside (or within the margin of) the rectangle: certainly touching
+    if (!(cx + mx < x0 || cx - mx > x1 || cy + my < y0 || cy - my > y1)) return true;
+    // exact conic vs rectangle, in coordinates local to the rectangle centre (well conditioned)
+    const float xm = 0.5f * (x0 + x1), ym = 0.5f * (y0 + y1), hw = 0.5f * (x1 - x0), hh = 0.5f * (y1 - y0);
+    const float k0 = fmaf(xm, q2.x, -q0.x), k1 = fmaf(xm, q2.y, -q0.y), k2 = fmaf(xm, q2.z, -q0.z);
+    const float l0 = fmaf(ym, q2.x, -q1.x), l1 = fmaf(ym, q2.y, -q1.y), l2 = fmaf(ym, q2.z, -q1.z);
+    const float Cx = k1 * l2 - k2 * l1, Cy = k2 * l0 - k0 * l2, Cz = k0 * l1 - k1 * l0;          // k x l
+    const float Ax = q2.y * l2 - q2.z * l1, Ay = q2.z * l0 - q2.x * l2, Az = q2.x * l1 - q2.y * l0;  // Tw x l
+    const float Bx = k1 * q2.z - k2 * q2.y, By = k2 * q2.x - k0 * q2.z, Bz = k0 * q2.y - k1 * q2.x;  // k x Tw
+    const float c = rho_max;
+    const float Fxx = Ax * Ax + Ay * Ay - c * (Az * Az), Fyy = Bx * Bx + By * By - c * (Bz * Bz);
+    const float Fxy = Ax * Bx + Ay * By - c * (Az * Bz);
+    const float Fx = Ax * Cx + Ay * Cy - c * (Az * Cz), Fy = Bx * Cx + By * Cy - c * (Bz * Cz);
+    const float F0 = Cx * Cx + Cy * Cy - c * (Cz * Cz);
+    if (!(Fxx > 0.f) || !(Fyy > 0.f)) return true;  // not the convex (ellipse) case after rounding: keep
+    // rounding margin: 1e-4 of the largest magnitude the terms of F can reach on the rectangle
+    const float Px = fabsf(Ax) * hw + fabsf(Bx) * hh + fabsf(Cx), Py = fabsf(Ay) * hw + fabsf(By) * hh + fabsf(Cy);
+    const float Pz = fabsf(Az) * hw + fabsf(Bz) * hh + fabsf(Cz);
+    const float margin = 1e-4f * (Px * Px + Py * Py + c * (Pz * Pz));
+    const float iFxx = 1.0f / Fxx, iFyy = 1.0f / Fyy;
+    float fmin_edges = 3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const float dy = e ? hh : -hh;  // horizontal edges: F(t, dy) = Fxx t^2 + 2 b t + cq
+        const float b = fmaf(Fxy, dy, Fx), cq = fmaf(fmaf(Fyy, dy, 2.f * Fy), dy, F0);
+        const float t = fminf(fmaxf(-b * iFxx, -hw), hw);
+        fmin_edges = fminf(fmin_edges, fmaf(fmaf(Fxx, t, 2.f * b), t, cq));
+        const float dx = e ? hw : -hw;  // vertical edges: F(dx, t) = Fyy t^2 + 2 b2 t + cq2
+        const float b2 = fmaf(Fxy, dx, Fy), cq2 = fmaf(fmaf(Fxx, dx, 2.f * Fx), dx, F0);
+        const float t2 = fminf(fmaxf(-b2 * iFyy, -hh), hh);
+        fmin_edges = fminf(fmin_edges, fmaf(fmaf(Fyy, t2, 2.f * b2), t2, cq2));
+    }
+    return !(fmin_edges > margin);  // NaN -> keep
 }
 
 // Part A of the per-(pixel, splat) work: ray-splat intersection and alpha (forward.cu:360-387; FMA form identical
@@ -355,6 +393,10 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 
     const int ridx = reduce16_index(lane);
     const bool writer = (lane & 3) == 0;
+    // Wave-uniform data-dependent shortcut: when no pixel of this quadrant carries an upstream gradient on the
+    // normal channels (SLAM's losses never touch them unless use_normal_loss), everything that only feeds
+    // dL_dnormal / the normal term of dL_dalpha is exactly zero and is skipped.  Results are unchanged.
+    const bool any_dn = __ballot(dn0 != 0.f || dn1 != 0.f || dn2 != 0.f) != 0;
     const int nbatches = (int)((max_last + 63) / 64);
     for (int b = nbatches - 1; b >= 0; b--) {
         const uint32_t b0 = (uint32_t)b * 64;
@@ -450,13 +492,14 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                     dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);
                     accum_alpha_rec = fmaf(1.f - last_alpha, accum_alpha_rec, last_alpha);
                     dL_dalpha = fmaf(1 - accum_alpha_rec, dL_daccum, dL_dalpha);
-                    // backward.cu:392-397
-                    an0 = fmaf(last_alpha, ln0, (1.f - last_alpha) * an0); ln0 = c3.x;
-                    dL_dalpha = fmaf(c3.x - an0, dn0, dL_dalpha); g[3] = w * dn0;
-                    an1 = fmaf(last_alpha, ln1, (1.f - last_alpha) * an1); ln1 = c3.y;
-                    dL_dalpha = fmaf(c3.y - an1, dn1, dL_dalpha); g[4] = w * dn1;
-                    an2 = fmaf(last_alpha, ln2, (1.f - last_alpha) * an2); ln2 = c3.z;
-                    dL_dalpha = fmaf(c3.z - an2, dn2, dL_dalpha); g[5] = w * dn2;
+                    if (any_dn) {  // backward.cu:392-397
+                        an0 = fmaf(last_alpha, ln0, (1.f - last_alpha) * an0); ln0 = c3.x;
+                        dL_dalpha = fmaf(c3.x - an0, dn0, dL_dalpha); g[3] = w * dn0;
+                        an1 = fmaf(last_alpha, ln1, (1.f - last_alpha) * an1); ln1 = c3.y;
+                        dL_dalpha = fmaf(c3.y - an1, dn1, dL_dalpha); g[4] = w * dn1;
+                        an2 = fmaf(last_alpha, ln2, (1.f - last_alpha) * an2); ln2 = c3.z;
+                        dL_dalpha = fmaf(c3.z - an2, dn2, dL_dalpha); g[5] = w * dn2;
+                    }
                     dL_dalpha *= T;
                     last_alpha = alpha;
                     dL_dalpha = fmaf(-T_final * ioma, bg_dot, dL_dalpha);
@@ -470,7 +513,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                         const float dp2 = -fmaf(dsx, s0, dsy * s1);
                         const float dk0 = fmaf(l1, dp2, -(l2 * dsy)), dk1 = fmaf(l2, dsx, -(l0 * dp2)), dk2 = fmaf(l0, dsy, -(l1 * dsx));
                         const float dl0 = fmaf(dsy, k2, -(dp2 * k1)), dl1 = fmaf(dp2, k0, -(dsx * k2)), dl2 = fmaf(dsx, k1, -(dsy * k0));
-                        g[6] = -dk0; g[7] = -dk1; g[8] = -dk2;
+                        g[6] = -dk0; g[7] = -dk1; g[8] = -dk2;  // sign folds into the v_fma source modifiers
                         g[9] = -dl0; g[10] = -dl1; g[11] = -dl2;
                         g[12] = fmaf(pxf, dk0, fmaf(pyf, dl0, dL_dz * s0));
                         g[13] = fmaf(pxf, dk1, fmaf(pyf, dl1, dL_dz * s1));
