@@ -217,6 +217,100 @@ radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __res
     }
 }
 
+// ---------------------------------------------------------------- per-tile depth sort (LDS)
+// After the global passes have binned the pairs by tile id (stable, so each tile's segment is still in Gaussian
+// order), one workgroup per tile sorts its segment by the 32 depth bits with a stable 4-pass LSD radix sort that
+// lives entirely in LDS ("LDS-staged per-tile splat lists").  The final order is identical to a global stable
+// sort on (tile | depth): LSD radix = sort by the low key first, then stably by the high key; here the high-key
+// pass simply ran first because the two keys are independent and the segment boundaries are known.
+// Segments longer than the LDS capacity take the same code path on global ping-pong buffers (flat pointers).
+__device__ void sort_segment_by_depth(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, int n,
+                                      uint32_t (*wcnt)[256])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = ((n + 255) / 256) * 64;  // contiguous elements per wave, multiple of 64
+    const int beg = wave * chunk, end = min(n, beg + chunk);
+    const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 8 * pass;
+        for (int i = threadIdx.x; i < 4 * 256; i += 256) (&wcnt[0][0])[i] = 0;
+        __syncthreads();
+        for (int i = beg + lane; i < end; i += 64) atomicAdd(&wcnt[wave][(ka[i] >> shift) & 255u], 1u);
+        __syncthreads();
+        {
+            const int d = threadIdx.x;
+            const uint32_t c0 = wcnt[0][d], c1 = wcnt[1][d], c2 = wcnt[2][d], c3 = wcnt[3][d];
+            const uint32_t tot = c0 + c1 + c2 + c3;
+            const uint32_t excl = block_incl_scan(tot, nullptr) - tot;
+            wcnt[0][d] = excl; wcnt[1][d] = excl + c0; wcnt[2][d] = excl + c0 + c1; wcnt[3][d] = excl + c0 + c1 + c2;
+        }
+        __syncthreads();
+        for (int i0 = beg; i0 < end; i0 += 64) {
+            const int i = i0 + lane;
+            const bool valid = i < end;
+            const uint32_t k = valid ? ka[i] : 0u;
+            const uint32_t v = valid ? va[i] : 0u;
+            const uint32_t d = (k >> shift) & 255u;
+            uint64_t peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const uint64_t vote = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? vote : ~vote;
+            }
+            const uint32_t before = wcnt[wave][d];
+            __builtin_amdgcn_wave_barrier();
+            if (valid && (peers & lt_mask) == 0) wcnt[wave][d] = before + (uint32_t)__popcll(peers);
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                const uint32_t dst = before + (uint32_t)__popcll(peers & lt_mask);
+                kb[dst] = k;
+                vb[dst] = v;
+            }
+        }
+        __syncthreads();
+        uint32_t* t = ka; ka = kb; kb = t;
+        t = va; va = vb; vb = t;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+tile_depth_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                       uint64_t* __restrict__ keys_alt, uint32_t* __restrict__ vals_alt, int cap)
+{
+    extern __shared__ uint32_t dyn[];  // [4][cap]: ka, va, kb, vb
+    __shared__ uint32_t wcnt[4][256];
+    const int tile = blockIdx.x;
+    const uint2 r = ranges[tile];
+    const int n = (int)(r.y - r.x);
+    if (n <= 1) return;
+    uint64_t* kseg = keys + r.x;
+    uint32_t* vseg = vals + r.x;
+    if (n <= cap) {
+        uint32_t *ka = dyn, *va = dyn + cap, *kb = dyn + 2 * cap, *vb = dyn + 3 * cap;
+        for (int i = threadIdx.x; i < n; i += 256) { ka[i] = (uint32_t)kseg[i]; va[i] = vseg[i]; }
+        __syncthreads();
+        sort_segment_by_depth(ka, va, kb, vb, n, wcnt);  // 4 passes: result back in ka / va
+        const uint64_t hi = (uint64_t)(uint32_t)tile << 32;
+        for (int i = threadIdx.x; i < n; i += 256) { kseg[i] = hi | ka[i]; vseg[i] = va[i]; }
+    } else {
+        // oversized list: same algorithm on global memory; the 32-bit depth keys are packed in place over the first
+        // half of each 64-bit slot array (segment-private scratch), then re-expanded.
+        uint32_t* ka = reinterpret_cast<uint32_t*>(kseg);             // n u32 inside the n u64 slots
+        uint32_t* kb = reinterpret_cast<uint32_t*>(keys_alt + r.x);
+        uint32_t* vb = vals_alt + r.x;
+        // compact depth bits front to back is unsafe in place (slot i/2 is read later), so stage through kb first
+        for (int i = threadIdx.x; i < n; i += 256) kb[i] = (uint32_t)kseg[i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) ka[i] = kb[i];
+        __syncthreads();
+        sort_segment_by_depth(ka, vseg, kb, vb, n, wcnt);
+        for (int i = threadIdx.x; i < n; i += 256) kb[i] = ka[i];
+        __syncthreads();
+        const uint64_t hi = (uint64_t)(uint32_t)tile << 32;
+        for (int i = threadIdx.x; i < n; i += 256) kseg[i] = hi | kb[i];
+    }
+}
+
 // rasterizer_impl.cu:116-138
 __global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges)
 {
@@ -251,20 +345,20 @@ void launch_duplicate(int P, const float4* rec, const float* depths, const uint3
                        keys, vals);
 }
 
-void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int end_bit,
-                       uint32_t* hist, size_t hist_elems, hipStream_t s)
+void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int begin_bit,
+                       int end_bit, uint32_t* hist, size_t hist_elems, hipStream_t s)
 {
     if (R <= 0) return;
     const int nblocks = (R + GS2D_SORT_ITEMS - 1) / GS2D_SORT_ITEMS;
     uint32_t* scan_tmp = hist + hist_elems;
     // data starts in the "b" buffers (unsorted) when the pass count is odd, so the result always lands in "a".
-    const int passes = (end_bit + 7) / 8;
+    const int passes = (end_bit - begin_bit + 7) / 8;
     uint64_t* kin = (passes & 1) ? keys_b : keys_a;
     uint32_t* vin = (passes & 1) ? vals_b : vals_a;
     uint64_t* kout = (passes & 1) ? keys_a : keys_b;
     uint32_t* vout = (passes & 1) ? vals_a : vals_b;
     for (int p = 0; p < passes; p++) {
-        const int shift = 8 * p;
+        const int shift = begin_bit + 8 * p;
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(SORT_T), 0, s, kin, R, shift, hist, nblocks);
         launch_inclusive_scan(hist, hist, (int)hist_elems, scan_tmp, nullptr, s);
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(SORT_T), 0, s, kin, vin, kout, vout, R, shift, hist,
@@ -272,6 +366,17 @@ void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys
         uint64_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
     }
+}
+
+void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt,
+                            uint32_t* vals_alt, hipStream_t s)
+{
+    if (R <= 0 || tiles <= 0) return;
+    // LDS capacity per tile: twice the mean list length, 2048 or 4096 elements (16 B each, <= 64 KB dynamic LDS)
+    const int avg = R / tiles;
+    const int cap = avg > 900 ? 4096 : 2048;
+    hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(tiles), dim3(256), (size_t)cap * 16, s, ranges, keys, vals, keys_alt,
+                       vals_alt, cap);
 }
 
 void launch_tile_ranges(int R, const uint64_t* keys, uint2* ranges, int tiles, hipStream_t s)

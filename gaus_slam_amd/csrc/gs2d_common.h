@@ -118,9 +118,13 @@ void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* 
 void launch_inclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* tmp, uint32_t* total_out, hipStream_t s);
 void launch_duplicate(int P, const float4* rec, const float* depths, const uint32_t* offsets, const int* radii,
                       int gx, int gy, uint64_t* keys, uint32_t* vals, hipStream_t s);
-// stable LSD radix sort of (u64 key, u32 val) pairs on key bits [0, end_bit). Result lands in keys_a/vals_a.
-void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int end_bit,
-                       uint32_t* hist, size_t hist_elems, hipStream_t s);
+// stable LSD radix sort of (u64 key, u32 val) pairs on key bits [begin_bit, end_bit). Result lands in keys_a/vals_a;
+// the unsorted input must sit in the "b" buffers when the pass count ceil((end-begin)/8) is odd, else in "a".
+void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int begin_bit,
+                       int end_bit, uint32_t* hist, size_t hist_elems, hipStream_t s);
+// one workgroup per tile: stable sort of the tile's segment by the low 32 key bits (depth), in LDS
+void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt,
+                            uint32_t* vals_alt, hipStream_t s);
 void launch_tile_ranges(int R, const uint64_t* keys, uint2* ranges, int tiles, hipStream_t s);
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
                       const float* bg, float* out_color, float* out_others, float* pix_state, int use_sa,

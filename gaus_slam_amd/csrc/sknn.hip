@@ -202,7 +202,7 @@ extern "C" int sknn_dist2(int N, const float* points, float* out, gs2d_alloc_fn 
     uint64_t* k_unsorted = (passes & 1) ? keys_alt : keys;
     uint32_t* v_unsorted = (passes & 1) ? vals_alt : order;
     hipLaunchKernelGGL(morton_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, points, bounds, k_unsorted, v_unsorted);
-    gs2d::launch_sort_pairs(N, keys, order, keys_alt, vals_alt, end_bit, hist, BL.hist_elems, s);
+    gs2d::launch_sort_pairs(N, keys, order, keys_alt, vals_alt, 0, end_bit, hist, BL.hist_elems, s);
     hipLaunchKernelGGL(gather_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, points, order, sorted);
     hipLaunchKernelGGL(box_bounds_kernel, dim3(nboxes), dim3(256), 0, s, N, sorted, boxes);
     hipLaunchKernelGGL(knn_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, sorted, order, boxes, nboxes, out);

@@ -205,3 +205,21 @@ def test_autograd_operator_surface(oracle):
         assert util.grad_err(params[name].grad.cpu().numpy(), go[k].reshape(params[name].shape)) <= 2e-4, name
     assert util.grad_err(means2D.grad.cpu().numpy(), go["dL_dmeans2D"]) <= 2e-4
     assert float(means2D.grad[:, 2].abs().max()) == 0
+
+
+def test_long_tile_lists_take_the_global_sort_path(oracle):
+    """Tile lists longer than the LDS capacity of the per-tile depth sort (4096) use the global-memory variant;
+    the order must still be bit-exact.  Many equal depths stress stability (ties keep Gaussian order)."""
+    P, W, H = 40000, 48, 32
+    sc = util.make_scene(P, W, H, seed=4, regime="tracking", scale_lo=2.0, scale_hi=12.0)
+    sc["means3D"][::3, 2] = 2.0  # exact depth ties
+    o = util.oracle_forward(oracle, sc, use_sa=True)
+    lens = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
+    assert lens.max() > 4096
+    h = util.hip_forward(sc, use_sa=True)
+    np.testing.assert_array_equal(h["keys"], o["keys"])
+    np.testing.assert_array_equal(h["point_list"], o["point_list"])
+    np.testing.assert_array_equal(h["ranges"], o["ranges"])
+    stable = (o["stability"] > KNIFE).reshape(H, W)
+    np.testing.assert_array_equal(h["last_contributor"][stable], o["n_contrib"][:H * W].reshape(H, W)[stable])
+    assert np.abs(h["color"] - o["color"])[:, stable].max() <= IMG_TOL
