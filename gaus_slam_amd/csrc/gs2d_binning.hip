@@ -373,8 +373,9 @@ void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* key
 {
     if (R <= 0 || tiles <= 0) return;
     // LDS capacity per tile: twice the mean list length, 2048 or 4096 elements (16 B each, <= 64 KB dynamic LDS)
+    // (smaller capacity = more workgroups per CU; the few tiles above it take the global-memory variant)
     const int avg = R / tiles;
-    const int cap = avg > 900 ? 4096 : 2048;
+    const int cap = avg > 1300 ? 4096 : 2048;
     hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(tiles), dim3(256), (size_t)cap * 16, s, ranges, keys, vals, keys_alt,
                        vals_alt, cap);
 }
