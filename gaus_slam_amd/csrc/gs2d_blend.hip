@@ -156,7 +156,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const uint2 range = ranges[tile];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
+    float T = 1.0f, C0_ = 0.f, C1_ = 0.f, C2_ = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
     float Dp = 0.f, M1 = 0.f, M2 = 0.f, D2 = 0.f, distortion = 0.f, median_depth = 0.f;
     uint32_t median_contributor = 0;  // the reference keeps a float initialised to -1 and stores (uint) -> 0
     uint32_t last_contributor = 0;
@@ -178,61 +178,68 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         uint64_t mask = __ballot(touch);
         if (mask == 0) continue;
         // software pipeline: the record of the NEXT surviving splat is fetched from LDS while the current one is
-        // evaluated, so the ds_read latency never sits on the critical path.
+        // evaluated, so the ds_read latency never sits on the critical path.  The loop is unrolled by two with the
+        // two register sets swapping roles (no c <- n copies: 20 v_movs per splat otherwise).
         int j = __builtin_ctzll(mask);
         mask &= mask - 1;
-        float4 c0 = wb.q[0][j], c1 = wb.q[1][j], c2 = wb.q[2][j], c3 = wb.q[3][j], c4 = wb.q[4][j];
-        for (;;) {
-            const bool more = mask != 0;
-            const int jn = more ? __builtin_ctzll(mask) : j;
-            mask &= mask - 1;  // no-op when mask == 0
-            const float4 n0 = wb.q[0][jn], n1 = wb.q[1][jn], n2 = wb.q[2][jn], n3 = wb.q[3][jn], n4 = wb.q[4][jn];
-            float alpha, depth;
-            bool ok;
-            fwd_eval(c0, c1, c2, pxf, pyf, alpha, depth, ok);
-            const float test_T = T * (1 - alpha);
-            const bool pass = ok && !done;
-            const bool stop = pass && test_T < 0.0001f;
-            done = done || stop;
-            if (pass && !stop) {
-                const uint32_t contributor = (base - range.x) + (uint32_t)j + 1u;
-                const float w = alpha * T;
-                if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }
-                if (USE_SA) {  // forward.cu:405-416
-                    if (Dp > 0) {
-                        const float exp_depth = median_depth;
-                        float exp_std = fmaf(fmaf(-2.0f * Dp, exp_depth, D2), fast_rcp(1 - T), exp_depth * exp_depth);
-                        exp_std = fmaxf(exp_std, 1e-7f);
-                        const float e = exp_depth - depth;
-                        const float conf = fast_exp(-(e * e) * fast_rcp(4 * exp_std));
-                        depth = fmaf(conf, depth, (1 - conf) * exp_depth);
-                    }
-                    Dp = fmaf(depth, w, Dp);
-                    D2 = fmaf(depth * depth, w, D2);
-                } else {  // forward.cu:417-423
-                    const float A = 1 - T;
-                    const float m = (GS2D_FAR_N / (GS2D_FAR_N - GS2D_NEAR_N)) * (1 - GS2D_NEAR_N * fast_rcp(depth));
-                    distortion = fmaf(fmaf(m * m, A, fmaf(-2.0f * m, M1, M2)), w, distortion);
-                    Dp = fmaf(depth, w, Dp);
-                    M1 = fmaf(m, w, M1);
-                    M2 = fmaf(m * m, w, M2);
-                }
-                N0 = fmaf(c3.x, w, N0); N1 = fmaf(c3.y, w, N1); N2 = fmaf(c3.z, w, N2);
-                C0 = fmaf(c3.w, w, C0); C1 = fmaf(c4.x, w, C1); C2 = fmaf(c4.y, w, C2);
-                T = test_T;
-                last_contributor = contributor;
-            }
-            if (!more || __ballot(!done) == 0) break;
-            c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4;
-            j = jn;
+        float4 a0 = wb.q[0][j], a1 = wb.q[1][j], a2 = wb.q[2][j], a3 = wb.q[3][j], a4 = wb.q[4][j];
+        float4 b0, b1, b2, b3, b4;
+#define GS2D_FWD_STEP(C0, C1, C2, C3, C4, N0_, N1_, N2_, N3_, N4_)                                                   \
+        {                                                                                                            \
+            const bool more = mask != 0;                                                                             \
+            const int jn = more ? __builtin_ctzll(mask) : j;                                                         \
+            mask &= mask - 1; /* no-op when mask == 0 */                                                             \
+            N0_ = wb.q[0][jn]; N1_ = wb.q[1][jn]; N2_ = wb.q[2][jn]; N3_ = wb.q[3][jn]; N4_ = wb.q[4][jn];           \
+            float alpha, depth;                                                                                      \
+            bool ok;                                                                                                 \
+            fwd_eval(C0, C1, C2, pxf, pyf, alpha, depth, ok);                                                        \
+            const float test_T = T * (1 - alpha);                                                                    \
+            const bool pass = ok && !done;                                                                           \
+            const bool stop = pass && test_T < 0.0001f;                                                              \
+            done = done || stop;                                                                                     \
+            if (pass && !stop) {                                                                                     \
+                const uint32_t contributor = (base - range.x) + (uint32_t)j + 1u;                                    \
+                const float w = alpha * T;                                                                           \
+                if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }                            \
+                if (USE_SA) { /* forward.cu:405-416 */                                                               \
+                    if (Dp > 0) {                                                                                    \
+                        const float exp_depth = median_depth;                                                        \
+                        float exp_std = fmaf(fmaf(-2.0f * Dp, exp_depth, D2), fast_rcp(1 - T), exp_depth * exp_depth); \
+                        exp_std = fmaxf(exp_std, 1e-7f);                                                             \
+                        const float e = exp_depth - depth;                                                           \
+                        const float conf = fast_exp(-(e * e) * fast_rcp(4 * exp_std));                               \
+                        depth = fmaf(conf, depth, (1 - conf) * exp_depth);                                           \
+                    }                                                                                                \
+                    Dp = fmaf(depth, w, Dp);                                                                         \
+                    D2 = fmaf(depth * depth, w, D2);                                                                 \
+                } else { /* forward.cu:417-423 */                                                                    \
+                    const float A = 1 - T;                                                                           \
+                    const float m = (GS2D_FAR_N / (GS2D_FAR_N - GS2D_NEAR_N)) * (1 - GS2D_NEAR_N * fast_rcp(depth)); \
+                    distortion = fmaf(fmaf(m * m, A, fmaf(-2.0f * m, M1, M2)), w, distortion);                       \
+                    Dp = fmaf(depth, w, Dp);                                                                         \
+                    M1 = fmaf(m, w, M1);                                                                             \
+                    M2 = fmaf(m * m, w, M2);                                                                         \
+                }                                                                                                    \
+                N0 = fmaf(C3.x, w, N0); N1 = fmaf(C3.y, w, N1); N2 = fmaf(C3.z, w, N2);                              \
+                C0_ = fmaf(C3.w, w, C0_); C1_ = fmaf(C4.x, w, C1_); C2_ = fmaf(C4.y, w, C2_);                        \
+                T = test_T;                                                                                          \
+                last_contributor = contributor;                                                                      \
+            }                                                                                                        \
+            if (!more || __ballot(!done) == 0) break;                                                                \
+            j = jn;                                                                                                  \
         }
+        for (;;) {
+            GS2D_FWD_STEP(a0, a1, a2, a3, a4, b0, b1, b2, b3, b4)
+            GS2D_FWD_STEP(b0, b1, b2, b3, b4, a0, a1, a2, a3, a4)
+        }
+#undef GS2D_FWD_STEP
     }
     if (inside) {  // forward.cu:441-466
         const size_t HW = (size_t)H * W;
         const size_t pix = (size_t)W * py + px;
-        out_color[pix] = fmaf(T, bg0, C0);
-        out_color[HW + pix] = fmaf(T, bg1, C1);
-        out_color[2 * HW + pix] = fmaf(T, bg2, C2);
+        out_color[pix] = fmaf(T, bg0, C0_);
+        out_color[HW + pix] = fmaf(T, bg1, C1_);
+        out_color[2 * HW + pix] = fmaf(T, bg2, C2_);
         const float dstd = fmaf(median_depth * median_depth, 1 - T, fmaf(-2.0f * median_depth, Dp, D2));
         out_others[pix] = Dp;
         out_others[HW + pix] = 1 - T;
@@ -415,133 +422,140 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         wave_lds_sync();
         uint64_t mask = __ballot(touch);
         if (mask == 0) continue;
-        // back to front; geometry of the next surviving splat is prefetched from LDS during the current one
+        // back to front; geometry of the next surviving splat is prefetched from LDS during the current one.
+        // Unrolled by two with the two geometry register sets swapping roles (no c <- n copies).
         int j = 63 - __builtin_clzll(mask);
         mask &= ~(1ull << j);
-        float4 c0 = wb.q[0][j], c1 = wb.q[1][j], c2 = wb.q[2][j];
-        for (;;) {
-            const bool more = mask != 0;
-            const int jn = more ? 63 - __builtin_clzll(mask) : j;
-            mask &= ~(1ull << jn);
-            const float4 n0 = wb.q[0][jn], n1 = wb.q[1][jn], n2 = wb.q[2][jn];
-            const float4 c3 = wb.q[3][j], c4 = wb.q[4][j];
-            const uint32_t contributor = b0 + (uint32_t)j;  // 0-based, as in backward.cu:285
-            bool active = inside && contributor < last_contributor;
-            if (__ballot(active) != 0) {
-                float g[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) g[i] = 0.f;
-                float g_mx = 0.f, g_my = 0.f;
-                bool lowpass = false;
-                const float k0 = fmaf(pxf, c2.x, -c0.x), k1 = fmaf(pxf, c2.y, -c0.y), k2 = fmaf(pxf, c2.z, -c0.z);
-                const float l0 = fmaf(pyf, c2.x, -c1.x), l1 = fmaf(pyf, c2.y, -c1.y), l2 = fmaf(pyf, c2.z, -c1.z);
-                const float p0 = fmaf(k1, l2, -(k2 * l1));
-                const float p1 = fmaf(k2, l0, -(k0 * l2));
-                const float p2 = fmaf(k0, l1, -(k1 * l0));
-                const float ip = fast_rcp(p2);
-                const float s0 = p0 * ip, s1 = p1 * ip;
-                const float rho3d = fmaf(s0, s0, s1 * s1);
-                const float d0 = c0.w - pxf, d1 = c1.w - pyf;
-                const float rho2d = GS2D_FILTER_INV_SQ * fmaf(d0, d0, d1 * d1);
-                const float rho = fminf(rho3d, rho2d);
-                float c_d = (rho3d <= rho2d) ? fmaf(s0, c2.x, fmaf(s1, c2.y, c2.z)) : c2.z;
-                const float power = -0.5f * rho;
-                const float G = fast_exp(power);
-                const float alpha = fminf(0.99f, c2.w * G);
-                active = active && !(p2 == 0.0f) && !(c_d < GS2D_NEAR_N) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                if (active) {
-                    const float ioma = fast_rcp(1.f - alpha);
-                    T = T * ioma;
-                    const float w = alpha * T;
-                    float dL_dalpha = 0.0f;
-                    // backward.cu:331-344
-                    ar0 = fmaf(last_alpha, lc0, (1.f - last_alpha) * ar0); lc0 = c3.w;
-                    dL_dalpha = fmaf(c3.w - ar0, dpx0, dL_dalpha); g[0] = w * dpx0;
-                    ar1 = fmaf(last_alpha, lc1, (1.f - last_alpha) * ar1); lc1 = c4.x;
-                    dL_dalpha = fmaf(c4.x - ar1, dpx1, dL_dalpha); g[1] = w * dpx1;
-                    ar2 = fmaf(last_alpha, lc2, (1.f - last_alpha) * ar2); lc2 = c4.y;
-                    dL_dalpha = fmaf(c4.y - ar2, dpx2, dL_dalpha); g[2] = w * dpx2;
-                    float conf = 1.f;
-                    if (USE_SA) {  // backward.cu:347-351
-                        if (T < 0.5f) {
-                            const float dm = c_d - mm;
-                            conf = fast_exp(-(dm * dm) * sa_k);
-                        }
-                        c_d = fmaf(c_d, conf, mm * (1 - conf));
-                    }
-                    float dL_dz = 0.0f, dL_dweight;
-                    if (contributor == median_contributor - 1u) dL_dz = dL_dmedian_depth;
-                    if (USE_SA) {
-                        const float dm = c_d - mm;
-                        dL_dweight = (dm * dm) * dL_dreg;
-                        dL_dalpha += dL_dweight - last_dL_dT;
-                        last_dL_dT = fmaf(dL_dweight, alpha, (1 - alpha) * last_dL_dT);
-                        dL_dz = fmaf(conf * 2.0f * w * dm, dL_dreg, dL_dz);
-                    } else {
-                        const float icd = fast_rcp(c_d);
-                        const float m_d = c1f * (1 - GS2D_NEAR_N * icd);
-                        const float dmd_dd = (c1f * GS2D_NEAR_N) * (icd * icd);
-                        dL_dweight = fmaf(m_d * m_d, final_A, fmaf(-2.0f * m_d, final_D, final_D2)) * dL_dreg;
-                        dL_dalpha += dL_dweight - last_dL_dT;
-                        last_dL_dT = fmaf(dL_dweight, alpha, (1 - alpha) * last_dL_dT);
-                        const float dL_dmd = 2.0f * w * fmaf(m_d, final_A, -final_D) * dL_dreg;
-                        dL_dz = fmaf(dL_dmd, dmd_dd, dL_dz);
-                    }
-                    accum_depth_rec = fmaf(last_alpha, last_depth, (1.f - last_alpha) * accum_depth_rec);
-                    last_depth = c_d;
-                    dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);
-                    accum_alpha_rec = fmaf(1.f - last_alpha, accum_alpha_rec, last_alpha);
-                    dL_dalpha = fmaf(1 - accum_alpha_rec, dL_daccum, dL_dalpha);
-                    if (any_dn) {  // backward.cu:392-397
-                        an0 = fmaf(last_alpha, ln0, (1.f - last_alpha) * an0); ln0 = c3.x;
-                        dL_dalpha = fmaf(c3.x - an0, dn0, dL_dalpha); g[3] = w * dn0;
-                        an1 = fmaf(last_alpha, ln1, (1.f - last_alpha) * an1); ln1 = c3.y;
-                        dL_dalpha = fmaf(c3.y - an1, dn1, dL_dalpha); g[4] = w * dn1;
-                        an2 = fmaf(last_alpha, ln2, (1.f - last_alpha) * an2); ln2 = c3.z;
-                        dL_dalpha = fmaf(c3.z - an2, dn2, dL_dalpha); g[5] = w * dn2;
-                    }
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha = fmaf(-T_final * ioma, bg_dot, dL_dalpha);
-                    const float dL_dG = c2.w * dL_dalpha;
-                    dL_dz = fmaf(conf * w, dL_ddepth, dL_dz);
-                    if (rho3d <= rho2d) {  // backward.cu:419-449
-                        const float gG = dL_dG * -G;
-                        const float dL_ds0 = fmaf(gG, s0, dL_dz * c2.x);
-                        const float dL_ds1 = fmaf(gG, s1, dL_dz * c2.y);
-                        const float dsx = dL_ds0 * ip, dsy = dL_ds1 * ip;
-                        const float dp2 = -fmaf(dsx, s0, dsy * s1);
-                        const float dk0 = fmaf(l1, dp2, -(l2 * dsy)), dk1 = fmaf(l2, dsx, -(l0 * dp2)), dk2 = fmaf(l0, dsy, -(l1 * dsx));
-                        const float dl0 = fmaf(dsy, k2, -(dp2 * k1)), dl1 = fmaf(dp2, k0, -(dsx * k2)), dl2 = fmaf(dsx, k1, -(dsy * k0));
-                        g[6] = -dk0; g[7] = -dk1; g[8] = -dk2;  // sign folds into the v_fma source modifiers
-                        g[9] = -dl0; g[10] = -dl1; g[11] = -dl2;
-                        g[12] = fmaf(pxf, dk0, fmaf(pyf, dl0, dL_dz * s0));
-                        g[13] = fmaf(pxf, dk1, fmaf(pyf, dl1, dL_dz * s1));
-                        g[14] = fmaf(pxf, dk2, fmaf(pyf, dl2, dL_dz));
-                    } else {  // backward.cu:450-457
-                        const float t = dL_dG * (-G * GS2D_FILTER_INV_SQ);
-                        g_mx = t * d0;
-                        g_my = t * d1;
-                        g[14] = dL_dz;
-                        lowpass = true;
-                    }
-                    g[15] = G * dL_dalpha;
-                }
-                if (__ballot(active) != 0) {
-                    float* dst = grad_rec + (size_t)__float_as_uint(c4.w) * GS2D_GRAD_FLOATS;
-                    const float tot = reduce16(g, lane);
-                    if (writer) atomicAdd(dst + ridx, tot);
-                    if (__ballot(lowpass) != 0) {
-                        g_mx = wave_sum_to_lane63(g_mx);
-                        g_my = wave_sum_to_lane63(g_my);
-                        if (lane == 63) { atomicAdd(dst + 16, g_mx); atomicAdd(dst + 17, g_my); }
-                    }
-                }
-            }
-            if (!more) break;
-            c0 = n0; c1 = n1; c2 = n2;
-            j = jn;
+        float4 ga0 = wb.q[0][j], ga1 = wb.q[1][j], ga2 = wb.q[2][j];
+        float4 gb0, gb1, gb2;
+#define GS2D_BWD_STEP(G0, G1, G2, N0_, N1_, N2_)                                                                      \
+        {                                                                                                             \
+            const bool more = mask != 0;                                                                              \
+            const int jn = more ? 63 - __builtin_clzll(mask) : j;                                                     \
+            mask &= ~(1ull << jn);                                                                                    \
+            N0_ = wb.q[0][jn]; N1_ = wb.q[1][jn]; N2_ = wb.q[2][jn];                                                  \
+            const float4 c3 = wb.q[3][j], c4 = wb.q[4][j];                                                            \
+            const uint32_t contributor = b0 + (uint32_t)j;  /* 0-based, as in backward.cu:285 */                      \
+            bool active = inside && contributor < last_contributor;                                                   \
+            if (__ballot(active) != 0) {                                                                              \
+                float g[16];                                                                                          \
+_Pragma("unroll")                                                                                                     \
+                for (int i = 0; i < 16; i++) g[i] = 0.f;                                                              \
+                float g_mx = 0.f, g_my = 0.f;                                                                         \
+                bool lowpass = false;                                                                                 \
+                const float k0 = fmaf(pxf, G2.x, -G0.x), k1 = fmaf(pxf, G2.y, -G0.y), k2 = fmaf(pxf, G2.z, -G0.z);    \
+                const float l0 = fmaf(pyf, G2.x, -G1.x), l1 = fmaf(pyf, G2.y, -G1.y), l2 = fmaf(pyf, G2.z, -G1.z);    \
+                const float p0 = fmaf(k1, l2, -(k2 * l1));                                                            \
+                const float p1 = fmaf(k2, l0, -(k0 * l2));                                                            \
+                const float p2 = fmaf(k0, l1, -(k1 * l0));                                                            \
+                const float ip = fast_rcp(p2);                                                                        \
+                const float s0 = p0 * ip, s1 = p1 * ip;                                                               \
+                const float rho3d = fmaf(s0, s0, s1 * s1);                                                            \
+                const float d0 = G0.w - pxf, d1 = G1.w - pyf;                                                         \
+                const float rho2d = GS2D_FILTER_INV_SQ * fmaf(d0, d0, d1 * d1);                                       \
+                const float rho = fminf(rho3d, rho2d);                                                                \
+                float c_d = (rho3d <= rho2d) ? fmaf(s0, G2.x, fmaf(s1, G2.y, G2.z)) : G2.z;                           \
+                const float power = -0.5f * rho;                                                                      \
+                const float G = fast_exp(power);                                                                      \
+                const float alpha = fminf(0.99f, G2.w * G);                                                           \
+                active = active && !(p2 == 0.0f) && !(c_d < GS2D_NEAR_N) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f); \
+                if (active) {                                                                                         \
+                    const float ioma = fast_rcp(1.f - alpha);                                                         \
+                    T = T * ioma;                                                                                     \
+                    const float w = alpha * T;                                                                        \
+                    float dL_dalpha = 0.0f;                                                                           \
+                    /* backward.cu:331-344 */                                                                         \
+                    ar0 = fmaf(last_alpha, lc0, (1.f - last_alpha) * ar0); lc0 = c3.w;                                \
+                    dL_dalpha = fmaf(c3.w - ar0, dpx0, dL_dalpha); g[0] = w * dpx0;                                   \
+                    ar1 = fmaf(last_alpha, lc1, (1.f - last_alpha) * ar1); lc1 = c4.x;                                \
+                    dL_dalpha = fmaf(c4.x - ar1, dpx1, dL_dalpha); g[1] = w * dpx1;                                   \
+                    ar2 = fmaf(last_alpha, lc2, (1.f - last_alpha) * ar2); lc2 = c4.y;                                \
+                    dL_dalpha = fmaf(c4.y - ar2, dpx2, dL_dalpha); g[2] = w * dpx2;                                   \
+                    float conf = 1.f;                                                                                 \
+                    if (USE_SA) {  /* backward.cu:347-351 */                                                          \
+                        if (T < 0.5f) {                                                                               \
+                            const float dm = c_d - mm;                                                                \
+                            conf = fast_exp(-(dm * dm) * sa_k);                                                       \
+                        }                                                                                             \
+                        c_d = fmaf(c_d, conf, mm * (1 - conf));                                                       \
+                    }                                                                                                 \
+                    float dL_dz = 0.0f, dL_dweight;                                                                   \
+                    if (contributor == median_contributor - 1u) dL_dz = dL_dmedian_depth;                             \
+                    if (USE_SA) {                                                                                     \
+                        const float dm = c_d - mm;                                                                    \
+                        dL_dweight = (dm * dm) * dL_dreg;                                                             \
+                        dL_dalpha += dL_dweight - last_dL_dT;                                                         \
+                        last_dL_dT = fmaf(dL_dweight, alpha, (1 - alpha) * last_dL_dT);                               \
+                        dL_dz = fmaf(conf * 2.0f * w * dm, dL_dreg, dL_dz);                                           \
+                    } else {                                                                                          \
+                        const float icd = fast_rcp(c_d);                                                              \
+                        const float m_d = c1f * (1 - GS2D_NEAR_N * icd);                                              \
+                        const float dmd_dd = (c1f * GS2D_NEAR_N) * (icd * icd);                                       \
+                        dL_dweight = fmaf(m_d * m_d, final_A, fmaf(-2.0f * m_d, final_D, final_D2)) * dL_dreg;        \
+                        dL_dalpha += dL_dweight - last_dL_dT;                                                         \
+                        last_dL_dT = fmaf(dL_dweight, alpha, (1 - alpha) * last_dL_dT);                               \
+                        const float dL_dmd = 2.0f * w * fmaf(m_d, final_A, -final_D) * dL_dreg;                       \
+                        dL_dz = fmaf(dL_dmd, dmd_dd, dL_dz);                                                          \
+                    }                                                                                                 \
+                    accum_depth_rec = fmaf(last_alpha, last_depth, (1.f - last_alpha) * accum_depth_rec);             \
+                    last_depth = c_d;                                                                                 \
+                    dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);                                    \
+                    accum_alpha_rec = fmaf(1.f - last_alpha, accum_alpha_rec, last_alpha);                            \
+                    dL_dalpha = fmaf(1 - accum_alpha_rec, dL_daccum, dL_dalpha);                                      \
+                    if (any_dn) {  /* backward.cu:392-397 */                                                          \
+                        an0 = fmaf(last_alpha, ln0, (1.f - last_alpha) * an0); ln0 = c3.x;                            \
+                        dL_dalpha = fmaf(c3.x - an0, dn0, dL_dalpha); g[3] = w * dn0;                                 \
+                        an1 = fmaf(last_alpha, ln1, (1.f - last_alpha) * an1); ln1 = c3.y;                            \
+                        dL_dalpha = fmaf(c3.y - an1, dn1, dL_dalpha); g[4] = w * dn1;                                 \
+                        an2 = fmaf(last_alpha, ln2, (1.f - last_alpha) * an2); ln2 = c3.z;                            \
+                        dL_dalpha = fmaf(c3.z - an2, dn2, dL_dalpha); g[5] = w * dn2;                                 \
+                    }                                                                                                 \
+                    dL_dalpha *= T;                                                                                   \
+                    last_alpha = alpha;                                                                               \
+                    dL_dalpha = fmaf(-T_final * ioma, bg_dot, dL_dalpha);                                             \
+                    const float dL_dG = G2.w * dL_dalpha;                                                             \
+                    dL_dz = fmaf(conf * w, dL_ddepth, dL_dz);                                                         \
+                    if (rho3d <= rho2d) {  /* backward.cu:419-449 */                                                  \
+                        const float gG = dL_dG * -G;                                                                  \
+                        const float dL_ds0 = fmaf(gG, s0, dL_dz * G2.x);                                              \
+                        const float dL_ds1 = fmaf(gG, s1, dL_dz * G2.y);                                              \
+                        const float dsx = dL_ds0 * ip, dsy = dL_ds1 * ip;                                             \
+                        const float dp2 = -fmaf(dsx, s0, dsy * s1);                                                   \
+                        const float dk0 = fmaf(l1, dp2, -(l2 * dsy)), dk1 = fmaf(l2, dsx, -(l0 * dp2)), dk2 = fmaf(l0, dsy, -(l1 * dsx)); \
+                        const float dl0 = fmaf(dsy, k2, -(dp2 * k1)), dl1 = fmaf(dp2, k0, -(dsx * k2)), dl2 = fmaf(dsx, k1, -(dsy * k0)); \
+                        g[6] = -dk0; g[7] = -dk1; g[8] = -dk2;  /* sign folds into the v_fma source modifiers */      \
+                        g[9] = -dl0; g[10] = -dl1; g[11] = -dl2;                                                      \
+                        g[12] = fmaf(pxf, dk0, fmaf(pyf, dl0, dL_dz * s0));                                           \
+                        g[13] = fmaf(pxf, dk1, fmaf(pyf, dl1, dL_dz * s1));                                           \
+                        g[14] = fmaf(pxf, dk2, fmaf(pyf, dl2, dL_dz));                                                \
+                    } else {  /* backward.cu:450-457 */                                                               \
+                        const float t = dL_dG * (-G * GS2D_FILTER_INV_SQ);                                            \
+                        g_mx = t * d0;                                                                                \
+                        g_my = t * d1;                                                                                \
+                        g[14] = dL_dz;                                                                                \
+                        lowpass = true;                                                                               \
+                    }                                                                                                 \
+                    g[15] = G * dL_dalpha;                                                                            \
+                }                                                                                                     \
+                if (__ballot(active) != 0) {                                                                          \
+                    float* dst = grad_rec + (size_t)__float_as_uint(c4.w) * GS2D_GRAD_FLOATS;                         \
+                    const float tot = reduce16(g, lane);                                                              \
+                    if (writer) atomicAdd(dst + ridx, tot);                                                           \
+                    if (__ballot(lowpass) != 0) {                                                                     \
+                        g_mx = wave_sum_to_lane63(g_mx);                                                              \
+                        g_my = wave_sum_to_lane63(g_my);                                                              \
+                        if (lane == 63) { atomicAdd(dst + 16, g_mx); atomicAdd(dst + 17, g_my); }                     \
+                    }                                                                                                 \
+                }                                                                                                     \
+            }                                                                                                         \
+            if (!more) break;                                                                                         \
+            j = jn;                                                                                                   \
         }
+        for (;;) {
+            GS2D_BWD_STEP(ga0, ga1, ga2, gb0, gb1, gb2)
+            GS2D_BWD_STEP(gb0, gb1, gb2, ga0, ga1, ga2)
+        }
+#undef GS2D_BWD_STEP
     }
 }
 
