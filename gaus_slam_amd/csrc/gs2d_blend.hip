@@ -25,6 +25,7 @@ __device__ __forceinline__ float bcast(float v, int lane)  // wave-uniform broad
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }          // v_rcp_f32, 1 ulp
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }         // v_sqrt_f32, 1 ulp
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }  // v_exp_f32
 
 // Conservative test "can this splat reach alpha >= 1/255 on any pixel of the rectangle [x0,x1] x [y0,y1]?",
@@ -45,18 +46,18 @@ __device__ __forceinline__ bool splat_may_touch(const float4 q0, const float4 q1
                                                 float x0, float x1, float y0, float y1)
 {
     if (!(rho_max >= 0.f)) return false;  // opacity*G can never reach 1/255 (NaN opacity is encoded as +huge)
-    const float rl = sqrtf(rho_max * (1.0f / GS2D_FILTER_INV_SQ)) + 0.5f;
+    const float rl = fast_sqrt(rho_max * (1.0f / GS2D_FILTER_INV_SQ)) + 0.5f;  // cull-only math: hardware sqrt/rcp, margins cover the ulps
     const bool lowpass_near = !(q0.w + rl < x0 || q0.w - rl > x1 || q1.w + rl < y0 || q1.w - rl > y1);
     const float a = rho_max * (q2.x * q2.x + q2.y * q2.y), zz = q2.z * q2.z;
     if (!(a <= 0.9f * zz) || !(q2.z > 0.f)) return true;  // disc not safely in front of the eye: no bound
-    const float inv = 1.0f / (a - zz);
+    const float inv = fast_rcp(a - zz);
     const float f0 = rho_max * inv, f2 = -inv;
     const float cx = f0 * (q0.x * q2.x + q0.y * q2.y) + f2 * (q0.z * q2.z);
     const float cy = f0 * (q1.x * q2.x + q1.y * q2.y) + f2 * (q1.z * q2.z);
     const float hx = cx * cx - (f0 * (q0.x * q0.x + q0.y * q0.y) + f2 * (q0.z * q0.z));
     const float hy = cy * cy - (f0 * (q1.x * q1.x + q1.y * q1.y) + f2 * (q1.z * q1.z));
     if (!(hx == hx) || !(hy == hy)) return true;
-    const float ex = sqrtf(fmaxf(hx, 0.f)), ey = sqrtf(fmaxf(hy, 0.f));
+    const float ex = fast_sqrt(fmaxf(hx, 0.f)), ey = fast_sqrt(fmaxf(hy, 0.f));
     const float mx = 0.5f + 0.02f * ex + 1e-4f * fabsf(cx), my = 0.5f + 0.02f * ey + 1e-4f * fabsf(cy);
     if (cx + ex + mx < x0 || cx - ex - mx > x1 || cy + ey + my < y0 || cy - ey - my > y1) return lowpass_near;
     if (lowpass_near) return true;
@@ -79,7 +80,7 @@ __device__ __forceinline__ bool splat_may_touch(const float4 q0, const float4 q1
     const float Px = fabsf(Ax) * hw + fabsf(Bx) * hh + fabsf(Cx), Py = fabsf(Ay) * hw + fabsf(By) * hh + fabsf(Cy);
     const float Pz = fabsf(Az) * hw + fabsf(Bz) * hh + fabsf(Cz);
     const float margin = 1e-4f * (Px * Px + Py * Py + c * (Pz * Pz));
-    const float iFxx = 1.0f / Fxx, iFyy = 1.0f / Fyy;
+    const float iFxx = fast_rcp(Fxx), iFyy = fast_rcp(Fyy);
     float fmin_edges = 3.0e38f;
 #pragma unroll
     for (int e = 0; e < 2; e++) {
@@ -435,30 +436,30 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             mask &= ~(1ull << jn);                                                                                    \
             N0_ = wb.q[0][jn]; N1_ = wb.q[1][jn]; N2_ = wb.q[2][jn];                                                  \
             const float4 c3 = wb.q[3][j], c4 = wb.q[4][j];                                                            \
-            const uint32_t contributor = b0 + (uint32_t)j;  /* 0-based, as in backward.cu:285 */                      \
+            const uint32_t contributor = b0 + (uint32_t)j; /* 0-based, as in backward.cu:285 */                       \
             bool active = inside && contributor < last_contributor;                                                   \
             if (__ballot(active) != 0) {                                                                              \
-                float g[16];                                                                                          \
-_Pragma("unroll")                                                                                                     \
-                for (int i = 0; i < 16; i++) g[i] = 0.f;                                                              \
-                float g_mx = 0.f, g_my = 0.f;                                                                         \
-                bool lowpass = false;                                                                                 \
+                /* Part A (all lanes): same geometry / alpha as the forward */                                        \
                 const float k0 = fmaf(pxf, G2.x, -G0.x), k1 = fmaf(pxf, G2.y, -G0.y), k2 = fmaf(pxf, G2.z, -G0.z);    \
                 const float l0 = fmaf(pyf, G2.x, -G1.x), l1 = fmaf(pyf, G2.y, -G1.y), l2 = fmaf(pyf, G2.z, -G1.z);    \
                 const float p0 = fmaf(k1, l2, -(k2 * l1));                                                            \
                 const float p1 = fmaf(k2, l0, -(k0 * l2));                                                            \
                 const float p2 = fmaf(k0, l1, -(k1 * l0));                                                            \
-                const float ip = fast_rcp(p2);                                                                        \
+                const float ip = p2 == 0.0f ? 0.0f : fast_rcp(p2); /* 0 keeps the skipped lanes finite */             \
                 const float s0 = p0 * ip, s1 = p1 * ip;                                                               \
                 const float rho3d = fmaf(s0, s0, s1 * s1);                                                            \
                 const float d0 = G0.w - pxf, d1 = G1.w - pyf;                                                         \
                 const float rho2d = GS2D_FILTER_INV_SQ * fmaf(d0, d0, d1 * d1);                                       \
                 const float rho = fminf(rho3d, rho2d);                                                                \
-                float c_d = (rho3d <= rho2d) ? fmaf(s0, G2.x, fmaf(s1, G2.y, G2.z)) : G2.z;                           \
+                const bool ray = rho3d <= rho2d;                                                                      \
+                float c_d = ray ? fmaf(s0, G2.x, fmaf(s1, G2.y, G2.z)) : G2.z;                                        \
                 const float power = -0.5f * rho;                                                                      \
                 const float G = fast_exp(power);                                                                      \
                 const float alpha = fminf(0.99f, G2.w * G);                                                           \
                 active = active && !(p2 == 0.0f) && !(c_d < GS2D_NEAR_N) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f); \
+                /* Part B (contributing lanes only): state recurrences; it leaves six "drivers" from which every      \
+                   gradient component follows linearly -- all zero for the lanes that do not contribute. */           \
+                float d_w = 0.f, d_gG = 0.f, d_zr = 0.f, d_zl = 0.f, d_t = 0.f, d_op = 0.f;                           \
                 if (active) {                                                                                         \
                     const float ioma = fast_rcp(1.f - alpha);                                                         \
                     T = T * ioma;                                                                                     \
@@ -466,13 +467,13 @@ _Pragma("unroll")                                                               
                     float dL_dalpha = 0.0f;                                                                           \
                     /* backward.cu:331-344 */                                                                         \
                     ar0 = fmaf(last_alpha, lc0, (1.f - last_alpha) * ar0); lc0 = c3.w;                                \
-                    dL_dalpha = fmaf(c3.w - ar0, dpx0, dL_dalpha); g[0] = w * dpx0;                                   \
+                    dL_dalpha = fmaf(c3.w - ar0, dpx0, dL_dalpha);                                                    \
                     ar1 = fmaf(last_alpha, lc1, (1.f - last_alpha) * ar1); lc1 = c4.x;                                \
-                    dL_dalpha = fmaf(c4.x - ar1, dpx1, dL_dalpha); g[1] = w * dpx1;                                   \
+                    dL_dalpha = fmaf(c4.x - ar1, dpx1, dL_dalpha);                                                    \
                     ar2 = fmaf(last_alpha, lc2, (1.f - last_alpha) * ar2); lc2 = c4.y;                                \
-                    dL_dalpha = fmaf(c4.y - ar2, dpx2, dL_dalpha); g[2] = w * dpx2;                                   \
+                    dL_dalpha = fmaf(c4.y - ar2, dpx2, dL_dalpha);                                                    \
                     float conf = 1.f;                                                                                 \
-                    if (USE_SA) {  /* backward.cu:347-351 */                                                          \
+                    if (USE_SA) { /* backward.cu:347-351 */                                                           \
                         if (T < 0.5f) {                                                                               \
                             const float dm = c_d - mm;                                                                \
                             conf = fast_exp(-(dm * dm) * sa_k);                                                       \
@@ -502,48 +503,48 @@ _Pragma("unroll")                                                               
                     dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);                                    \
                     accum_alpha_rec = fmaf(1.f - last_alpha, accum_alpha_rec, last_alpha);                            \
                     dL_dalpha = fmaf(1 - accum_alpha_rec, dL_daccum, dL_dalpha);                                      \
-                    if (any_dn) {  /* backward.cu:392-397 */                                                          \
+                    if (any_dn) { /* backward.cu:392-397 */                                                           \
                         an0 = fmaf(last_alpha, ln0, (1.f - last_alpha) * an0); ln0 = c3.x;                            \
-                        dL_dalpha = fmaf(c3.x - an0, dn0, dL_dalpha); g[3] = w * dn0;                                 \
+                        dL_dalpha = fmaf(c3.x - an0, dn0, dL_dalpha);                                                 \
                         an1 = fmaf(last_alpha, ln1, (1.f - last_alpha) * an1); ln1 = c3.y;                            \
-                        dL_dalpha = fmaf(c3.y - an1, dn1, dL_dalpha); g[4] = w * dn1;                                 \
+                        dL_dalpha = fmaf(c3.y - an1, dn1, dL_dalpha);                                                 \
                         an2 = fmaf(last_alpha, ln2, (1.f - last_alpha) * an2); ln2 = c3.z;                            \
-                        dL_dalpha = fmaf(c3.z - an2, dn2, dL_dalpha); g[5] = w * dn2;                                 \
+                        dL_dalpha = fmaf(c3.z - an2, dn2, dL_dalpha);                                                 \
                     }                                                                                                 \
                     dL_dalpha *= T;                                                                                   \
                     last_alpha = alpha;                                                                               \
                     dL_dalpha = fmaf(-T_final * ioma, bg_dot, dL_dalpha);                                             \
                     const float dL_dG = G2.w * dL_dalpha;                                                             \
                     dL_dz = fmaf(conf * w, dL_ddepth, dL_dz);                                                         \
-                    if (rho3d <= rho2d) {  /* backward.cu:419-449 */                                                  \
-                        const float gG = dL_dG * -G;                                                                  \
-                        const float dL_ds0 = fmaf(gG, s0, dL_dz * G2.x);                                              \
-                        const float dL_ds1 = fmaf(gG, s1, dL_dz * G2.y);                                              \
-                        const float dsx = dL_ds0 * ip, dsy = dL_ds1 * ip;                                             \
-                        const float dp2 = -fmaf(dsx, s0, dsy * s1);                                                   \
-                        const float dk0 = fmaf(l1, dp2, -(l2 * dsy)), dk1 = fmaf(l2, dsx, -(l0 * dp2)), dk2 = fmaf(l0, dsy, -(l1 * dsx)); \
-                        const float dl0 = fmaf(dsy, k2, -(dp2 * k1)), dl1 = fmaf(dp2, k0, -(dsx * k2)), dl2 = fmaf(dsx, k1, -(dsy * k0)); \
-                        g[6] = -dk0; g[7] = -dk1; g[8] = -dk2;  /* sign folds into the v_fma source modifiers */      \
-                        g[9] = -dl0; g[10] = -dl1; g[11] = -dl2;                                                      \
-                        g[12] = fmaf(pxf, dk0, fmaf(pyf, dl0, dL_dz * s0));                                           \
-                        g[13] = fmaf(pxf, dk1, fmaf(pyf, dl1, dL_dz * s1));                                           \
-                        g[14] = fmaf(pxf, dk2, fmaf(pyf, dl2, dL_dz));                                                \
-                    } else {  /* backward.cu:450-457 */                                                               \
-                        const float t = dL_dG * (-G * GS2D_FILTER_INV_SQ);                                            \
-                        g_mx = t * d0;                                                                                \
-                        g_my = t * d1;                                                                                \
-                        g[14] = dL_dz;                                                                                \
-                        lowpass = true;                                                                               \
-                    }                                                                                                 \
-                    g[15] = G * dL_dalpha;                                                                            \
+                    d_w = w;                                                                                          \
+                    d_op = G * dL_dalpha;                                                                             \
+                    d_gG = ray ? dL_dG * -G : 0.f;                         /* backward.cu:419-449 */                  \
+                    d_zr = ray ? dL_dz : 0.f;                                                                         \
+                    d_zl = ray ? 0.f : dL_dz;                              /* backward.cu:450-457 */                  \
+                    d_t = ray ? 0.f : dL_dG * (-G * GS2D_FILTER_INV_SQ);                                              \
                 }                                                                                                     \
                 if (__ballot(active) != 0) {                                                                          \
+                    float g[16];                                                                                      \
+                    g[0] = d_w * dpx0; g[1] = d_w * dpx1; g[2] = d_w * dpx2;                                          \
+                    g[3] = d_w * dn0; g[4] = d_w * dn1; g[5] = d_w * dn2;                                             \
+                    const float dL_ds0 = fmaf(d_gG, s0, d_zr * G2.x);                                                 \
+                    const float dL_ds1 = fmaf(d_gG, s1, d_zr * G2.y);                                                 \
+                    const float dsx = dL_ds0 * ip, dsy = dL_ds1 * ip;                                                 \
+                    const float dp2 = -fmaf(dsx, s0, dsy * s1);                                                       \
+                    const float dk0 = fmaf(l1, dp2, -(l2 * dsy)), dk1 = fmaf(l2, dsx, -(l0 * dp2)), dk2 = fmaf(l0, dsy, -(l1 * dsx)); \
+                    const float dl0 = fmaf(dsy, k2, -(dp2 * k1)), dl1 = fmaf(dp2, k0, -(dsx * k2)), dl2 = fmaf(dsx, k1, -(dsy * k0)); \
+                    g[6] = -dk0; g[7] = -dk1; g[8] = -dk2;                                                            \
+                    g[9] = -dl0; g[10] = -dl1; g[11] = -dl2;                                                          \
+                    g[12] = fmaf(pxf, dk0, fmaf(pyf, dl0, d_zr * s0));                                                \
+                    g[13] = fmaf(pxf, dk1, fmaf(pyf, dl1, d_zr * s1));                                                \
+                    g[14] = fmaf(pxf, dk2, fmaf(pyf, dl2, d_zr)) + d_zl;                                              \
+                    g[15] = d_op;                                                                                     \
                     float* dst = grad_rec + (size_t)__float_as_uint(c4.w) * GS2D_GRAD_FLOATS;                         \
                     const float tot = reduce16(g, lane);                                                              \
                     if (writer) atomicAdd(dst + ridx, tot);                                                           \
-                    if (__ballot(lowpass) != 0) {                                                                     \
-                        g_mx = wave_sum_to_lane63(g_mx);                                                              \
-                        g_my = wave_sum_to_lane63(g_my);                                                              \
+                    if (__ballot(d_t != 0.f) != 0) {                                                                  \
+                        const float g_mx = wave_sum_to_lane63(d_t * d0);                                              \
+                        const float g_my = wave_sum_to_lane63(d_t * d1);                                              \
                         if (lane == 63) { atomicAdd(dst + 16, g_mx); atomicAdd(dst + 17, g_my); }                     \
                     }                                                                                                 \
                 }                                                                                                     \
