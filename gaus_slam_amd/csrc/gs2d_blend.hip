@@ -27,6 +27,10 @@ __device__ __forceinline__ float bcast(float v, int lane)  // wave-uniform broad
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }          // v_rcp_f32, 1 ulp
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }         // v_sqrt_f32, 1 ulp
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }  // v_exp_f32
+// exp(-0.5 r) and exp(-q/4) with the power-of-two factors folded into the log2(e) constant: scaling by 2^k commutes
+// with rounding, so these return exactly fast_exp(-0.5f * r) / fast_exp(-(q * 0.25f)) with one multiply less.
+__device__ __forceinline__ float fast_exp_neg_half(float r) { return __builtin_amdgcn_exp2f(r * -0.72134752044448170368f); }
+__device__ __forceinline__ float fast_exp_neg_quarter(float q) { return __builtin_amdgcn_exp2f(q * -0.36067376022224085184f); }
 
 // Conservative test "can this splat reach alpha >= 1/255 on any pixel of the rectangle [x0,x1] x [y0,y1]?",
 // evaluated by the lane that holds the splat record.  rho_max = 2 ln(255 opacity) (+margin, precomputed by the
@@ -114,9 +118,9 @@ __device__ __forceinline__ void fwd_eval(const float4 q0, const float4 q1, const
     const float rho2d = GS2D_FILTER_INV_SQ * fmaf(d0, d0, d1 * d1);
     const float rho = fminf(rho3d, rho2d);
     depth = (rho3d <= rho2d) ? fmaf(s0, q2.x, fmaf(s1, q2.y, q2.z)) : q2.z;
-    const float power = -0.5f * rho;
-    alpha = fminf(0.99f, q2.w * fast_exp(power));
-    ok = !(p2 == 0.0f) && !(depth < GS2D_NEAR_N) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+    alpha = fminf(0.99f, q2.w * fast_exp_neg_half(rho));
+    // power = -0.5 rho > 0  <=>  rho < 0
+    ok = !(p2 == 0.0f) && !(depth < GS2D_NEAR_N) && !(rho < 0.0f) && !(alpha < 1.0f / 255.0f);
 }
 
 // Wave-private LDS staging of one 64-splat batch: lane i writes record i, any lane reads record j as a
@@ -208,7 +212,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                         float exp_std = fmaf(fmaf(-2.0f * Dp, exp_depth, D2), fast_rcp(1 - T), exp_depth * exp_depth); \
                         exp_std = fmaxf(exp_std, 1e-7f);                                                             \
                         const float e = exp_depth - depth;                                                           \
-                        const float conf = fast_exp(-(e * e) * fast_rcp(4 * exp_std));                               \
+                        const float conf = fast_exp_neg_quarter((e * e) * fast_rcp(exp_std));                                \
                         depth = fmaf(conf, depth, (1 - conf) * exp_depth);                                           \
                     }                                                                                                \
                     Dp = fmaf(depth, w, Dp);                                                                         \
@@ -453,10 +457,9 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                 const float rho = fminf(rho3d, rho2d);                                                                \
                 const bool ray = rho3d <= rho2d;                                                                      \
                 float c_d = ray ? fmaf(s0, G2.x, fmaf(s1, G2.y, G2.z)) : G2.z;                                        \
-                const float power = -0.5f * rho;                                                                      \
-                const float G = fast_exp(power);                                                                      \
+                const float G = fast_exp_neg_half(rho);                                                               \
                 const float alpha = fminf(0.99f, G2.w * G);                                                           \
-                active = active && !(p2 == 0.0f) && !(c_d < GS2D_NEAR_N) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f); \
+                active = active && !(p2 == 0.0f) && !(c_d < GS2D_NEAR_N) && !(rho < 0.0f) && !(alpha < 1.0f / 255.0f); \
                 /* Part B (contributing lanes only): state recurrences; it leaves six "drivers" from which every      \
                    gradient component follows linearly -- all zero for the lanes that do not contribute. */           \
                 float d_w = 0.f, d_gG = 0.f, d_zr = 0.f, d_zl = 0.f, d_t = 0.f, d_op = 0.f;                           \
