@@ -203,11 +203,14 @@ int gs2d_forward(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_alloc_f
     uint2* ranges = (uint2*)(img + IL.ranges);
     float* pix_state = (float*)(img + IL.pix);
 
-    // Sort = (a) stable radix passes on the tile-id bits only [32, 32+bit) -> pairs binned by tile, Gaussian order
-    // kept inside a tile; (b) tile ranges; (c) per-tile stable depth sort in LDS.  Same final order as the
-    // reference's single 64-bit SortPairs on bits [0, 32+bit) (rasterizer_impl.cu:306-314).
-    const int end_bit = 32 + (int)higher_msb((uint32_t)(cam.gx * cam.gy));
-    const int passes = (end_bit - 32 + 7) / 8;
+    // Sort = (a) stable binning of the pairs by tile id (single counting-sort pass; 8-bit radix passes on the tile
+    // bits when there are too many tiles for LDS), Gaussian order kept inside a tile; (b) tile ranges; (c) per-tile
+    // stable depth sort in LDS.  Same final order as the reference's single 64-bit SortPairs on bits [0, 32+bit)
+    // (rasterizer_impl.cu:306-314).
+    const int tile_bits = (int)higher_msb((uint32_t)(cam.gx * cam.gy));
+    const int end_bit = 32 + tile_bits;
+    const bool one_pass = IL.tiles <= GS2D_BIN_MAX_TILES;
+    const int passes = one_pass ? 1 : (end_bit - 32 + 7) / 8;
     if (R > 0) {
         // unsorted pairs go where the ping-pong needs them so that the result lands in (keys, point_list)
         uint64_t* k_unsorted = (passes & 1) ? keys_alt : keys;
@@ -217,13 +220,19 @@ int gs2d_forward(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_alloc_f
         g_timer.end(ST_DUPLICATE, s);
         GS2D_STAGE("duplicate");
         g_timer.begin(ST_SORT, s);
-        gs2d::launch_sort_pairs(R, keys, point_list, keys_alt, vals_alt, 32, end_bit, hist, BL.hist_elems, s);
+        if (one_pass) {
+            gs2d::launch_bin_by_tile(R, IL.tiles, tile_bits, k_unsorted, v_unsorted, keys, point_list, hist, ranges, s);
+        } else {
+            gs2d::launch_sort_pairs(R, keys, point_list, keys_alt, vals_alt, 32, end_bit, hist, BL.hist_elems, s);
+        }
         GS2D_STAGE("bin by tile");
     }
-    g_timer.begin(ST_RANGES, s);
-    gs2d::launch_tile_ranges(R, keys, ranges, IL.tiles, s);
-    g_timer.end(ST_RANGES, s);
-    GS2D_STAGE("ranges");
+    if (R == 0 || !one_pass) {
+        g_timer.begin(ST_RANGES, s);
+        gs2d::launch_tile_ranges(R, keys, ranges, IL.tiles, s);
+        g_timer.end(ST_RANGES, s);
+        GS2D_STAGE("ranges");
+    }
     if (R > 0) {
         gs2d::launch_tile_depth_sort(R, IL.tiles, ranges, keys, point_list, keys_alt, vals_alt, s);
         g_timer.end(ST_SORT, s);

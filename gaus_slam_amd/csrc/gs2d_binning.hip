@@ -217,6 +217,78 @@ radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __res
     }
 }
 
+// ---------------------------------------------------------------- single-pass binning by tile id
+// Counting sort on the whole tile id (up to GS2D_BIN_MAX_TILES bins) in ONE pass: per-workgroup tile histogram ->
+// device scan -> stable scatter.  Replaces ceil(bits/8) passes of the generic 8-bit sort and yields the tile
+// ranges for free (they are the scanned histogram's tile boundaries).
+constexpr int BIN_T = 256;
+constexpr int BIN_ITEMS = 8192;             // instances per workgroup
+constexpr int BIN_WAVE_ITEMS = BIN_ITEMS / 4;
+
+// hist[tile * nblocks + block]
+__global__ void __launch_bounds__(BIN_T)
+bin_hist_kernel(const uint64_t* __restrict__ keys, int n, int ntiles, uint32_t* __restrict__ hist, int nblocks)
+{
+    extern __shared__ uint32_t lds[];  // [ntiles]
+    for (int t = threadIdx.x; t < ntiles; t += BIN_T) lds[t] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * BIN_ITEMS;
+    const int end = min(n, base + BIN_ITEMS);
+    for (int i = base + threadIdx.x; i < end; i += BIN_T) atomicAdd(&lds[(uint32_t)(keys[i] >> 32)], 1u);
+    __syncthreads();
+    for (int t = threadIdx.x; t < ntiles; t += BIN_T) hist[(size_t)t * nblocks + blockIdx.x] = lds[t];
+}
+
+// offs_incl = inclusive scan of hist (same indexing).  Stable: element order inside a tile is preserved.
+__global__ void __launch_bounds__(BIN_T)
+bin_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
+                   uint32_t* __restrict__ vals_out, int n, int ntiles, int nbits, const uint32_t* __restrict__ offs_incl,
+                   int nblocks, uint2* __restrict__ ranges)
+{
+    extern __shared__ uint32_t lds[];  // [4][ntiles] per-wave counts, then running destinations
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = threadIdx.x; t < 4 * ntiles; t += BIN_T) lds[t] = 0;
+    __syncthreads();
+    const int wbeg = blockIdx.x * BIN_ITEMS + wave * BIN_WAVE_ITEMS;
+    const int wend = min(n, wbeg + BIN_WAVE_ITEMS);
+    uint32_t* mine = lds + wave * ntiles;
+    for (int i = wbeg + lane; i < wend; i += 64) atomicAdd(&mine[(uint32_t)(keys_in[i] >> 32)], 1u);
+    __syncthreads();
+    for (int t = threadIdx.x; t < ntiles; t += BIN_T) {
+        const size_t hidx = (size_t)t * nblocks + blockIdx.x;
+        const uint32_t c0 = lds[t], c1 = lds[ntiles + t], c2 = lds[2 * ntiles + t], c3 = lds[3 * ntiles + t];
+        const uint32_t start = offs_incl[hidx] - (c0 + c1 + c2 + c3);
+        lds[t] = start; lds[ntiles + t] = start + c0; lds[2 * ntiles + t] = start + c0 + c1; lds[3 * ntiles + t] = start + c0 + c1 + c2;
+        if (blockIdx.x == 0) {  // tile ranges = boundaries of the scanned histogram (rasterizer_impl.cu:116-138 semantics)
+            const uint32_t tbeg = t == 0 ? 0u : offs_incl[(size_t)t * nblocks - 1];
+            const uint32_t tend = offs_incl[(size_t)(t + 1) * nblocks - 1];
+            ranges[t] = tend > tbeg ? make_uint2(tbeg, tend) : make_uint2(0u, 0u);
+        }
+    }
+    __syncthreads();
+    const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int i0 = wbeg; i0 < wend; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < wend;
+        const uint64_t k = valid ? keys_in[i] : 0ull;
+        const uint32_t d = (uint32_t)(k >> 32);
+        uint64_t peers = __ballot(valid);
+        for (int b = 0; b < nbits; b++) {
+            const uint64_t vote = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? vote : ~vote;
+        }
+        const uint32_t before = valid ? mine[d] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers & lt_mask) == 0) mine[d] = before + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            const uint32_t dst = before + (uint32_t)__popcll(peers & lt_mask);
+            keys_out[dst] = k;
+            vals_out[dst] = vals_in[i];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- per-tile depth sort (LDS)
 // After the global passes have binned the pairs by tile id (stable, so each tile's segment is still in Gaussian
 // order), one workgroup per tile sorts its segment by the 32 depth bits with a stable 4-pass LSD radix sort that
@@ -366,6 +438,20 @@ void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys
         uint64_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
     }
+}
+
+bool launch_bin_by_tile(int R, int tiles, int nbits, const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out,
+                        uint32_t* vals_out, uint32_t* hist, uint2* ranges, hipStream_t s)
+{
+    if (tiles > GS2D_BIN_MAX_TILES) return false;  // caller falls back to the 8-bit passes + tile_ranges kernel
+    const int nblocks = (R + BIN_ITEMS - 1) / BIN_ITEMS;
+    const size_t hist_elems = (size_t)tiles * nblocks;
+    uint32_t* scan_tmp = hist + hist_elems;
+    hipLaunchKernelGGL(bin_hist_kernel, dim3(nblocks), dim3(BIN_T), (size_t)tiles * 4, s, keys_in, R, tiles, hist, nblocks);
+    launch_inclusive_scan(hist, hist, (int)hist_elems, scan_tmp, nullptr, s);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblocks), dim3(BIN_T), (size_t)tiles * 16, s, keys_in, vals_in, keys_out, vals_out,
+                       R, tiles, nbits, hist, nblocks, ranges);
+    return true;
 }
 
 void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt,

@@ -43,6 +43,8 @@ struct ImgLayout {
 
 #define GS2D_SCAN_ITEMS 1024  // elements per workgroup in the device scan
 #define GS2D_SORT_ITEMS 2048  // elements per workgroup in one radix pass (256 threads x 8)
+#define GS2D_BIN_ITEMS 8192   // elements per workgroup in the single-pass tile binning
+#define GS2D_BIN_MAX_TILES 4096  // 4 waves x tiles x 4 B of LDS counters must fit 64 KB
 
 static inline GeomLayout geom_layout(int P)
 {
@@ -73,8 +75,11 @@ static inline BinLayout bin_layout(int R)
     L.keys_alt = o; o = gs2d_align_up(o + 8 * r, 256);
     const size_t nblk = (r + GS2D_SORT_ITEMS - 1) / GS2D_SORT_ITEMS;
     L.hist_elems = 256 * nblk;
-    const size_t scan_blk = (L.hist_elems + GS2D_SCAN_ITEMS - 1) / GS2D_SCAN_ITEMS;
-    L.hist = o; o = gs2d_align_up(o + 4 * (L.hist_elems + scan_blk + 64), 256);
+    // the single-pass tile binning needs tiles x ceil(R / GS2D_BIN_ITEMS) counters; size for the larger of the two
+    const size_t bin_elems = (size_t)GS2D_BIN_MAX_TILES * ((r + GS2D_BIN_ITEMS - 1) / GS2D_BIN_ITEMS);
+    const size_t cap_elems = L.hist_elems > bin_elems ? L.hist_elems : bin_elems;
+    const size_t scan_blk = (cap_elems + GS2D_SCAN_ITEMS - 1) / GS2D_SCAN_ITEMS;
+    L.hist = o; o = gs2d_align_up(o + 4 * (cap_elems + scan_blk + 64), 256);
     L.total = o;
     return L;
 }
@@ -122,6 +127,10 @@ void launch_duplicate(int P, const float4* rec, const float* depths, const uint3
 // the unsorted input must sit in the "b" buffers when the pass count ceil((end-begin)/8) is odd, else in "a".
 void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int begin_bit,
                        int end_bit, uint32_t* hist, size_t hist_elems, hipStream_t s);
+// single-pass stable counting sort of the pairs by tile id (key >> 32) that also writes the tile ranges;
+// returns false (nothing launched) when there are more than GS2D_BIN_MAX_TILES tiles
+bool launch_bin_by_tile(int R, int tiles, int nbits, const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out,
+                        uint32_t* vals_out, uint32_t* hist, uint2* ranges, hipStream_t s);
 // one workgroup per tile: stable sort of the tile's segment by the low 32 key bits (depth), in LDS
 void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt,
                             uint32_t* vals_alt, hipStream_t s);

@@ -326,6 +326,10 @@ void orc_tile_ranges(int64_t R, const uint64_t* keys_sorted, int ntiles, uint32_
     }
 }
 
+/* diagnostic counters (pairs evaluated before saturation / pairs passing the alpha test); read via orc_get_stats */
+static uint64_t orc_stats[2];
+void orc_get_stats(uint64_t* out, int reset) { out[0] = orc_stats[0]; out[1] = orc_stats[1]; if (reset) { orc_stats[0] = 0; orc_stats[1] = 0; } }
+
 static inline float relm(float a, float b) /* relative distance of a from threshold b */
 {
     return fabsf(a - b) / fabsf(b);
@@ -361,8 +365,10 @@ void orc_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_l
                 float median_contributor = -1;
                 uint32_t contributor = 0, last_contributor = 0;
                 float margin = 1e30f;
+                uint64_t n_eval = 0, n_pass = 0;
                 for (uint32_t it = r0; it < r1; it++) {
                     contributor++;
+                    n_eval++;
                     const uint32_t g = point_list[it];
                     const float* Tm = transMats + 9 * (size_t)g;
                     const float Tu[3] = {Tm[0], Tm[1], Tm[2]}, Tv[3] = {Tm[3], Tm[4], Tm[5]},
@@ -388,6 +394,7 @@ void orc_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_l
                     const float alpha = fmin_c(0.99f, no[3] * expf(power));
                     if (stab) margin = fminf(margin, relm(alpha, 1.0f / 255.0f));
                     if (alpha < 1.0f / 255.0f) continue;
+                    n_pass++;
                     if (stab) {
                         margin = fminf(margin, relm(depth, NEAR_N));
                         const float mx = fmaxf(rho3d, rho2d);
@@ -424,6 +431,10 @@ void orc_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_l
                     last_contributor = contributor;
                 }
                 /* forward.cu:441-466 */
+#pragma omp atomic
+                orc_stats[0] += n_eval;
+#pragma omp atomic
+                orc_stats[1] += n_pass;
                 final_T[pix] = T;
                 n_contrib[pix] = last_contributor;
                 for (int ch = 0; ch < 3; ch++) out_color[ch * HW + pix] = fmaf(T, bg[ch], C[ch]);

@@ -223,3 +223,30 @@ def test_long_tile_lists_take_the_global_sort_path(oracle):
     stable = (o["stability"] > KNIFE).reshape(H, W)
     np.testing.assert_array_equal(h["last_contributor"][stable], o["n_contrib"][:H * W].reshape(H, W)[stable])
     assert np.abs(h["color"] - o["color"])[:, stable].max() <= IMG_TOL
+
+
+def test_replica_shaped_1200x680(oracle):
+    """Replica native 1200x680 (75x43 = 3225 tiles -> 12 tile-id bits), 600k surfels,
+    tracking regime (identity view)."""
+    P, W, H = 600000, 1200, 680
+    sc = util.make_scene(P, W, H, seed=2, regime="tracking")
+    oracle.set_threads(os.cpu_count() or 1)
+    o = util.oracle_forward(oracle, sc, use_sa=True)
+    assert o["nbits"] == 32 + 12
+    h = util.hip_forward(sc, use_sa=True)
+    assert h["num_rendered"] == o["num_rendered"]
+    np.testing.assert_array_equal(h["point_list"], o["point_list"])
+    np.testing.assert_array_equal(h["ranges"], o["ranges"])
+    stable = (o["stability"] > KNIFE).reshape(H, W)
+    assert (~stable).mean() < 5e-3
+    np.testing.assert_array_equal(h["last_contributor"][stable], o["n_contrib"][:H * W].reshape(H, W)[stable])
+    assert np.abs(h["color"] - o["color"])[:, stable].max() <= IMG_TOL
+    assert np.abs(h["allmap"] - o["allmap"])[:, stable].max() <= IMG_TOL
+    dc, da = util.make_upstream_grads(W, H, channels=(0, 1))  # tracking loss touches colour, depth, alpha
+    dc, da = (dc * W * H).numpy(), (da * W * H).numpy()
+    dc[:, ~stable] = 0; da[:, ~stable] = 0
+    go = oracle.backward(o, dc, da)
+    gh = util.hip_backward(h, dc, da)
+    for k in ["dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations"]:
+        assert util.grad_err(gh[k], go[k].reshape(gh[k].shape)) <= GRAD_TOL, k
+    oracle.set_threads(1)
