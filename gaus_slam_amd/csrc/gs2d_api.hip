@@ -133,14 +133,17 @@ void gs2d_image_layout(int width, int height, size_t o[2])
     o[0] = L.ranges; o[1] = L.pix;
 }
 
-int gs2d_forward(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_alloc_fn binning_alloc, void* binning_user,
-                 gs2d_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
-                 int height, const float* means3D, const float* shs, const float* colors_precomp,
-                 const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                 const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
-                 const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
-                 float* out_others, int* radii, int use_sa, int debug, void* stream)
+int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_alloc_fn binning_alloc, void* binning_user,
+                       gs2d_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                       int height, const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                       const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
+                       const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                       float* out_others, int* radii, int use_sa, int debug, const float* pose_Rt, const float* pose_quat,
+                       void* stream)
 {
+    if ((pose_Rt == nullptr) != (pose_quat == nullptr)) return fail_msg("pose_Rt and pose_quat must be given together");
+    if (pose_Rt != nullptr && transMat_precomp != nullptr) return fail_msg("a pose cannot be combined with transMat_precomp");
     (void)tan_fovx; (void)tan_fovy; (void)prefiltered;  // unused by the reference forward kernels as well (forward.cu:165)
     hipStream_t s = (hipStream_t)stream;
     if (P < 0 || width <= 0 || height <= 0) return fail_msg("bad sizes");
@@ -173,7 +176,7 @@ int gs2d_forward(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_alloc_f
 
     g_timer.begin(ST_PREPROCESS, s);
     gs2d::launch_preprocess_fwd(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, transMat_precomp,
-                                colors_precomp, cam, radii, depths, rec, tiles_touched, clamped, s);
+                                colors_precomp, cam, radii, depths, rec, tiles_touched, clamped, pose_Rt, pose_quat, s);
     g_timer.end(ST_PREPROCESS, s);
     GS2D_STAGE("preprocess");
 
@@ -246,15 +249,33 @@ int gs2d_forward(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_alloc_f
     return R;
 }
 
-int gs2d_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
-                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                  const float* rotations, const float* transMat_precomp, const float* viewmatrix,
-                  const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
-                  char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix,
-                  const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor,
-                  float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot, int use_sa,
-                  int debug, void* stream)
+int gs2d_forward(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_alloc_fn binning_alloc, void* binning_user,
+                 gs2d_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                 int height, const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                 const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                 float* out_others, int* radii, int use_sa, int debug, void* stream)
 {
+    return gs2d_forward_posed(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M,
+                              background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                              rotations, transMat_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
+                              out_color, out_others, radii, use_sa, debug, nullptr, nullptr, stream);
+}
+
+int gs2d_backward_posed(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                        const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                        const float* rotations, const float* transMat_precomp, const float* viewmatrix,
+                        const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                        char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix,
+                        const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor,
+                        float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot, int use_sa,
+                        int debug, const float* pose_Rt, const float* pose_quat, float* dL_dpose, void* stream)
+{
+    if ((pose_Rt == nullptr) != (pose_quat == nullptr)) return fail_msg("pose_Rt and pose_quat must be given together");
+    if (pose_Rt != nullptr && dL_dpose == nullptr) return fail_msg("dL_dpose is required with a pose");
+    if (dL_dpose != nullptr)
+        GS2D_CHECK(hipMemsetAsync(dL_dpose, 0, sizeof(float) * 12, (hipStream_t)stream), "memset dL_dpose");
     (void)colors_precomp; (void)transMat_precomp; (void)scale_modifier;
     hipStream_t s = (hipStream_t)stream;
     if (P <= 0) return 0;
@@ -289,10 +310,26 @@ int gs2d_backward(int P, int D, int M, int R, const float* background, int width
     g_timer.begin(ST_PREPROCESS_BWD, s);
     gs2d::launch_preprocess_bwd(P, D, M, means3D, rec, radii, shs, clamped, scales, rotations, cam, grad_rec,
                                 dL_dtransMat, dL_dnormal, dL_dcolor, dL_dopacity, dL_dsh, dL_dmean2D, dL_dmean3D,
-                                dL_dscale, dL_drot, s);
+                                dL_dscale, dL_drot, pose_Rt, pose_quat, pose_Rt ? dL_dpose : nullptr, s);
     g_timer.end(ST_PREPROCESS_BWD, s);
     GS2D_STAGE("preprocess_bwd");
     return 0;
+}
+
+int gs2d_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                  const float* rotations, const float* transMat_precomp, const float* viewmatrix,
+                  const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                  char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix,
+                  const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor,
+                  float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot, int use_sa,
+                  int debug, void* stream)
+{
+    return gs2d_backward_posed(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier,
+                               rotations, transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii,
+                               geom_buffer, binning_buffer, img_buffer, dL_dpix, dL_depths, dL_dmean2D, dL_dnormal,
+                               dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot, use_sa, debug,
+                               nullptr, nullptr, nullptr, stream);
 }
 
 int gs2d_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,

@@ -112,12 +112,13 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
                            const float* rotations, const float* opacities, const float* shs,
                            const float* transMat_precomp, const float* colors_precomp, const CamParams& cam,
                            int* radii, float* depths, float4* rec, uint32_t* tiles_touched, uint8_t* clamped,
-                           hipStream_t s);
+                           const float* pose_Rt, const float* pose_q, hipStream_t s);
 void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float4* rec, const int* radii,
                            const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
                            const CamParams& cam, const float* grad_rec, float* dL_dtransMat, float* dL_dnormal,
                            float* dL_dcolor, float* dL_dopacity, float* dL_dsh, float* dL_dmean2D,
-                           float* dL_dmean3D, float* dL_dscale, float* dL_drot, hipStream_t s);
+                           float* dL_dmean3D, float* dL_dscale, float* dL_drot, const float* pose_Rt, const float* pose_q,
+                           float* dL_dpose, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
 // inclusive scan of n u32; tmp must hold ceil(n/1024)+64 u32. If total_out != nullptr the grand total is stored there.
 void launch_inclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* tmp, uint32_t* total_out, hipStream_t s);

@@ -89,11 +89,36 @@ __device__ __forceinline__ void compute_transmat(const float px, const float py,
     normal[2] = (vm[2] * lx + vm[6] * ly) + vm[10] * lz;
 }
 
+
+// Optional rigid pose applied inside the preprocess kernels (tracking regime of the reference,
+// render/__init__.py:31-36: means3D_cam = R x + t, rotations = q_cam (x) q, rendered with an identity view).
+// pose_Rt: 12 floats, row-major [R | t]; pose_q: q_cam as (w,x,y,z).  Expression order is part of the
+// bit-exact contract with oracle/gs2d_oracle.py::compose_pose.
+__device__ __forceinline__ void pose_point(const float* Rt, float& x, float& y, float& z)
+{
+    const float nx = ((Rt[0] * x + Rt[1] * y) + Rt[2] * z) + Rt[3];
+    const float ny = ((Rt[4] * x + Rt[5] * y) + Rt[6] * z) + Rt[7];
+    const float nz = ((Rt[8] * x + Rt[9] * y) + Rt[10] * z) + Rt[11];
+    x = nx; y = ny; z = nz;
+}
+// pytorch3d quaternion_multiply(a, b) = standardize(raw_multiply(a, b)), real part first
+__device__ __forceinline__ float4 pose_quat(const float* a, const float4 b, float& sign)
+{
+    const float aw = a[0], ax = a[1], ay = a[2], az = a[3];
+    float ow = ((aw * b.x - ax * b.y) - ay * b.z) - az * b.w;
+    float ox = ((aw * b.y + ax * b.x) + ay * b.w) - az * b.z;
+    float oy = ((aw * b.z - ax * b.w) + ay * b.x) + az * b.y;
+    float oz = ((aw * b.w + ax * b.z) - ay * b.y) + az * b.x;
+    sign = ow < 0.f ? -1.f : 1.f;
+    if (ow < 0.f) { ow = -ow; ox = -ox; oy = -oy; oz = -oz; }
+    return make_float4(ow, ox, oy, oz);
+}
+
 // forward.cu:20-71
-__device__ void sh_to_rgb(int idx, int deg, int M, const float* means, const float* campos, const float* shs,
+__device__ void sh_to_rgb(int idx, int deg, int M, float posx, float posy, float posz, const float* campos, const float* shs,
                           uint8_t* clamped, float out[3])
 {
-    const float dx = means[3 * idx] - campos[0], dy = means[3 * idx + 1] - campos[1], dz = means[3 * idx + 2] - campos[2];
+    const float dx = posx - campos[0], dy = posy - campos[1], dz = posz - campos[2];
     const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
     const float x = dx / len, y = dy / len, z = dz / len;
     const float* sh = shs + (size_t)idx * M * 3;
@@ -128,7 +153,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       const float* __restrict__ shs, const float* __restrict__ transMat_precomp,
                       const float* __restrict__ colors_precomp, const CamParams cam, int* __restrict__ radii,
                       float* __restrict__ depths, float4* __restrict__ rec, uint32_t* __restrict__ tiles_touched,
-                      uint8_t* __restrict__ clamped)
+                      uint8_t* __restrict__ clamped, const float* __restrict__ pose_Rt, const float* __restrict__ pose_q)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P) return;
@@ -138,7 +163,8 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     float out_depth = 0.f;
     float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0, r4 = r0;
 
-    const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+    float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+    if (pose_Rt != nullptr) pose_point(pose_Rt, px, py, pz);
     const float* vm = cam.vm;
     const float pvx = ((vm[0] * px + vm[4] * py) + vm[8] * pz) + vm[12];
     const float pvy = ((vm[1] * px + vm[5] * py) + vm[9] * pz) + vm[13];
@@ -147,7 +173,8 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         if (pvz <= 0.2f) break;  // auxiliary.h:199
         float T[9], normal[3];
         if (transMat_precomp == nullptr) {
-            const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+            float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+            if (pose_q != nullptr) { float sgn; q = pose_quat(pose_q, q, sgn); }
             const float2 sc = reinterpret_cast<const float2*>(scales)[idx];
             float w, x, y, z;
             const Mat3 R = quat_to_R(q, w, x, y, z);
@@ -180,7 +207,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         get_rect(cx, cy, f2i_sat(radius), cam.gx, cam.gy, minx, miny, maxx, maxy);
         if ((maxx - minx) * (maxy - miny) == 0) break;
         float col[3];
-        if (colors_precomp == nullptr) sh_to_rgb(idx, D, M, means3D, cam.campos, shs, clamped, col);
+        if (colors_precomp == nullptr) sh_to_rgb(idx, D, M, px, py, pz, cam.campos, shs, clamped, col);
         else { col[0] = colors_precomp[3 * idx]; col[1] = colors_precomp[3 * idx + 1]; col[2] = colors_precomp[3 * idx + 2]; }
         out_depth = pvz;
         out_radius = f2i_sat(radius);
@@ -203,10 +230,10 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 }
 
 // backward.cu:20-139
-__device__ void sh_backward(int idx, int deg, int M, const float* means, const float* campos, const float* shs,
+__device__ void sh_backward(int idx, int deg, int M, float posx, float posy, float posz, const float* campos, const float* shs,
                             const uint8_t* clamped, const float dL_dcolor[3], float dL_dmean[3], float* dL_dshs)
 {
-    const float ox = means[3 * idx] - campos[0], oy = means[3 * idx + 1] - campos[1], oz = means[3 * idx + 2] - campos[2];
+    const float ox = posx - campos[0], oy = posy - campos[1], oz = posz - campos[2];
     const float len = sqrtf((ox * ox + oy * oy) + oz * oz);
     const float x = ox / len, y = oy / len, z = oz / len;
     const float* sh = shs + (size_t)idx * M * 3;
@@ -268,19 +295,20 @@ __device__ void sh_backward(int idx, int deg, int M, const float* means, const f
     dL_dmean[2] += (-ox * oz * ddir[0] - oy * oz * ddir[1] + (sum2 - oz * oz) * ddir[2]) * invsum32;
 }
 
-// backward.cu:466-664.  Reads the packed gradient record written by the backward blend, writes the
-// public gradient tensors (all pre-zeroed by the caller, so culled Gaussians stay zero).
-__global__ void __launch_bounds__(256)
-preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float4* __restrict__ rec,
-                      const int* __restrict__ radii, const float* __restrict__ shs,
-                      const uint8_t* __restrict__ clamped, const float* __restrict__ scales,
-                      const float* __restrict__ rotations, const CamParams cam, const float* __restrict__ grad_rec,
-                      float* __restrict__ dL_dtransMat, float* __restrict__ dL_dnormal, float* __restrict__ dL_dcolor,
-                      float* __restrict__ dL_dopacity, float* __restrict__ dL_dsh, float* __restrict__ dL_dmean2D,
-                      float* __restrict__ dL_dmean3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
+// backward.cu:466-664 for one Gaussian.  Reads the packed gradient record written by the backward blend and writes
+// every element of the public gradient tensors (zeros for Gaussians culled by the forward).  With a pose
+// (tracking regime) means/rotations are transformed exactly as in the forward, dL_dmean3D / dL_drot are mapped back
+// to the untransformed parameters and pg[12] receives this Gaussian's share of dL/d[R|t].
+__device__ __forceinline__ void
+preprocess_bwd_one(int idx, int P, int D, int M, const float* __restrict__ means3D, const float4* __restrict__ rec,
+                   const int* __restrict__ radii, const float* __restrict__ shs, const uint8_t* __restrict__ clamped,
+                   const float* __restrict__ scales, const float* __restrict__ rotations, const CamParams& cam,
+                   const float* __restrict__ grad_rec, float* __restrict__ dL_dtransMat, float* __restrict__ dL_dnormal,
+                   float* __restrict__ dL_dcolor, float* __restrict__ dL_dopacity, float* __restrict__ dL_dsh,
+                   float* __restrict__ dL_dmean2D, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dscale,
+                   float* __restrict__ dL_drot, const float* __restrict__ pose_Rt, const float* __restrict__ pose_q, float pg[12])
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
+    (void)P;
     if (!(radii[idx] > 0)) {
         // culled in the forward: every gradient is exactly zero (the reference gets this from torch::zeros,
         // rasterize_points.cu:192-200; here the kernel writes it so the caller can hand in uninitialised memory)
@@ -317,19 +345,22 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const float dmx = g[16], dmy = g[17];
 
     const bool precomp = (scales == nullptr);
-    const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+    const float wx = means3D[3 * idx], wy = means3D[3 * idx + 1], wz = means3D[3 * idx + 2];  // untransformed
+    float px = wx, py = wy, pz = wz;
+    if (pose_Rt != nullptr) pose_point(pose_Rt, px, py, pz);
     const float* pm = cam.pm;
     const float* vm = cam.vm;
     float T[9], normal[3] = {0.f, 0.f, 0.f};
     float Pm[4][3];
     Mat3 R;
-    float sx = 0.f, sy = 0.f, w = 0.f, x = 0.f, y = 0.f, z = 0.f;
+    float sx = 0.f, sy = 0.f, w = 0.f, x = 0.f, y = 0.f, z = 0.f, qsign = 1.f;
     const float4* rp = rec + (size_t)idx * GS2D_REC_F4;
     const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
     if (precomp) {
         T[0] = q0.x; T[1] = q0.y; T[2] = q0.z; T[3] = q1.x; T[4] = q1.y; T[5] = q1.z; T[6] = q2.x; T[7] = q2.y; T[8] = q2.z;
     } else {
-        const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+        float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+        if (pose_q != nullptr) q = pose_quat(pose_q, q, qsign);
         const float2 sc = reinterpret_cast<const float2*>(scales)[idx];
         sx = sc.x; sy = sc.y;  // backward.cu:504: scale_modifier is ignored here
         R = quat_to_R(q, w, x, y, z);
@@ -388,6 +419,14 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         dq.y = 2.f * (-2.f * x * (v[1][1] + v[2][2]) + y * (v[1][0] + v[0][1]) + z * (v[2][0] + v[0][2]) + w * (v[2][1] - v[1][2]));
         dq.z = 2.f * (x * (v[1][0] + v[0][1]) - 2.f * y * (v[0][0] + v[2][2]) + z * (v[2][1] + v[1][2]) + w * (v[0][2] - v[2][0]));
         dq.w = 2.f * (x * (v[2][0] + v[0][2]) + y * (v[2][1] + v[1][2]) - 2.f * z * (v[0][0] + v[1][1]) + w * (v[1][0] - v[0][1]));
+        if (pose_q != nullptr) {  // dL/dq = sign * L(q_cam)^T dL/dq'
+            const float aw = pose_q[0], ax = pose_q[1], ay = pose_q[2], az = pose_q[3];
+            const float4 t = dq;
+            dq.x = qsign * (((aw * t.x + ax * t.y) + ay * t.z) + az * t.w);
+            dq.y = qsign * (((-ax * t.x + aw * t.y) + az * t.z) - ay * t.w);
+            dq.z = qsign * (((-ay * t.x - az * t.y) + aw * t.z) + ax * t.w);
+            dq.w = qsign * (((-az * t.x + ay * t.y) - ax * t.z) + aw * t.w);
+        }
         reinterpret_cast<float4*>(dL_drot)[idx] = dq;
         float2 ds;
         ds.x = (dh[0][0] * R.m[0][0] + dh[0][1] * R.m[1][0]) + dh[0][2] * R.m[2][0];
@@ -397,10 +436,20 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         have_mean = true;
     }
     if (shs != nullptr) {
-        sh_backward(idx, D, M, means3D, cam.campos, shs, clamped, dcol, dmean, dL_dsh);
+        sh_backward(idx, D, M, px, py, pz, cam.campos, shs, clamped, dcol, dmean, dL_dsh);
         have_mean = true;
     }
     (void)have_mean;
+    if (pose_Rt != nullptr) {
+        // x_cam = R x + t:  dL/dR = g (x) x, dL/dt = g, dL/dx = R^T g
+        const float g0 = dmean[0], g1 = dmean[1], g2 = dmean[2];
+        pg[0] = g0 * wx; pg[1] = g0 * wy; pg[2] = g0 * wz; pg[3] = g0;
+        pg[4] = g1 * wx; pg[5] = g1 * wy; pg[6] = g1 * wz; pg[7] = g1;
+        pg[8] = g2 * wx; pg[9] = g2 * wy; pg[10] = g2 * wz; pg[11] = g2;
+        dmean[0] = (pose_Rt[0] * g0 + pose_Rt[4] * g1) + pose_Rt[8] * g2;
+        dmean[1] = (pose_Rt[1] * g0 + pose_Rt[5] * g1) + pose_Rt[9] * g2;
+        dmean[2] = (pose_Rt[2] * g0 + pose_Rt[6] * g1) + pose_Rt[10] * g2;
+    }
     dL_dmean3D[3 * idx] = dmean[0]; dL_dmean3D[3 * idx + 1] = dmean[1]; dL_dmean3D[3 * idx + 2] = dmean[2];
     if (precomp || early) {  // no scale / rotation gradient on these paths (backward.cu:565-579)
         dL_dscale[2 * idx] = 0.f; dL_dscale[2 * idx + 1] = 0.f;
@@ -415,6 +464,43 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     dL_dmean2D[3 * idx + 1] = (float)((double)(dTout[5] * depth) * 0.5 * (double)(float)cam.H);
     dL_dmean2D[3 * idx + 2] = 0.f;
 }
+
+__global__ void __launch_bounds__(256)
+preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float4* __restrict__ rec,
+                      const int* __restrict__ radii, const float* __restrict__ shs,
+                      const uint8_t* __restrict__ clamped, const float* __restrict__ scales,
+                      const float* __restrict__ rotations, const CamParams cam, const float* __restrict__ grad_rec,
+                      float* __restrict__ dL_dtransMat, float* __restrict__ dL_dnormal, float* __restrict__ dL_dcolor,
+                      float* __restrict__ dL_dopacity, float* __restrict__ dL_dsh, float* __restrict__ dL_dmean2D,
+                      float* __restrict__ dL_dmean3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
+                      const float* __restrict__ pose_Rt, const float* __restrict__ pose_q, float* __restrict__ dL_dpose)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    // pose gradient: sum_i g_i (x) x_i and sum_i g_i over the Gaussians of this workgroup, then 12 atomics
+    float pg[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) pg[i] = 0.f;
+    if (idx < P) preprocess_bwd_one(idx, P, D, M, means3D, rec, radii, shs, clamped, scales, rotations, cam, grad_rec, dL_dtransMat,
+                                    dL_dnormal, dL_dcolor, dL_dopacity, dL_dsh, dL_dmean2D, dL_dmean3D, dL_dscale, dL_drot, pose_Rt,
+                                    pose_q, pg);
+    if (dL_dpose != nullptr) {
+        __shared__ float red[4][12];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            float v = pg[i];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            if (lane == 0) red[wave][i] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 12) {
+            const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+            if (v != 0.f) atomicAdd(dL_dpose + threadIdx.x, v);
+        }
+    }
+}
+
 
 // rasterizer_impl.cu:54-66
 __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ vm,
@@ -435,22 +521,23 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
                            const float* rotations, const float* opacities, const float* shs,
                            const float* transMat_precomp, const float* colors_precomp, const CamParams& cam,
                            int* radii, float* depths, float4* rec, uint32_t* tiles_touched, uint8_t* clamped,
-                           hipStream_t s)
+                           const float* pose_Rt, const float* pose_q, hipStream_t s)
 {
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, transMat_precomp, colors_precomp, cam, radii, depths,
-                       rec, tiles_touched, clamped);
+                       rec, tiles_touched, clamped, pose_Rt, pose_q);
 }
 
 void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float4* rec, const int* radii,
                            const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
                            const CamParams& cam, const float* grad_rec, float* dL_dtransMat, float* dL_dnormal,
                            float* dL_dcolor, float* dL_dopacity, float* dL_dsh, float* dL_dmean2D,
-                           float* dL_dmean3D, float* dL_dscale, float* dL_drot, hipStream_t s)
+                           float* dL_dmean3D, float* dL_dscale, float* dL_drot, const float* pose_Rt, const float* pose_q,
+                           float* dL_dpose, hipStream_t s)
 {
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, rec, radii, shs,
                        clamped, scales, rotations, cam, grad_rec, dL_dtransMat, dL_dnormal, dL_dcolor, dL_dopacity,
-                       dL_dsh, dL_dmean2D, dL_dmean3D, dL_dscale, dL_drot);
+                       dL_dsh, dL_dmean2D, dL_dmean3D, dL_dscale, dL_drot, pose_Rt, pose_q, dL_dpose);
 }
 
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s)

@@ -55,9 +55,10 @@ def _stream_ptr(device):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        use_sa, prefiltered, debug):
+                        use_sa, prefiltered, debug, pose_Rt=None, pose_quat=None):
     """_C.rasterize_gaussians (rasterize_points.cu:39-138): returns
-    (num_rendered, out_color[3,H,W], out_others[7,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer)."""
+    (num_rendered, out_color[3,H,W], out_others[7,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer).
+    pose_Rt [3,4] / pose_quat [4] (extension, see gs2d_forward_posed): rigid transform fused into the preprocess."""
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     for name, t in (("background", background), ("means3D", means3D), ("colors", colors), ("opacity", opacity),
@@ -81,11 +82,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                    viewmatrix, projmatrix, campos)]
         bg_, m3_, sh_, col_, op_, sc_, rot_, tm_, vm_, pm_, cp_ = keep
         with torch.cuda.device(dev):
-            rendered = L.gs2d_forward(
+            prt_ = _f32c(pose_Rt) if pose_Rt is not None else None
+            pq_ = _f32c(pose_quat) if pose_quat is not None else None
+            rendered = L.gs2d_forward_posed(
                 geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg_), W, H, _ptr(m3_),
                 _ptr(sh_), _ptr(col_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(tm_), _ptr(vm_),
                 _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), out_color.data_ptr(),
-                out_others.data_ptr(), radii.data_ptr(), int(bool(use_sa)), int(bool(debug)), _stream_ptr(dev))
+                out_others.data_ptr(), radii.data_ptr(), int(bool(use_sa)), int(bool(debug)), _ptr(prt_), _ptr(pq_),
+                _stream_ptr(dev))
         if rendered < 0:
             raise RuntimeError(_lib.last_error())
     return rendered, out_color, out_others, radii, geom.tensor, binning.tensor, img.tensor
@@ -94,7 +98,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, use_sa,
-                                 debug):
+                                 debug, pose_Rt=None, pose_quat=None):
     """_C.rasterize_gaussians_backward (rasterize_points.cu:140-239): returns
     (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dtransMat[P,9], dL_dsh[P,M,3],
      dL_dscales[P,2], dL_drotations[P,4])."""
@@ -118,15 +122,25 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         bg_, m3_, sh_, col_, sc_, rot_, tm_, vm_, pm_, cp_, dc_, do_ = keep
         radii_ = radii.contiguous()
         with torch.cuda.device(dev):
-            rc = L.gs2d_backward(
+            prt_ = _f32c(pose_Rt) if pose_Rt is not None else None
+            pq_ = _f32c(pose_quat) if pose_quat is not None else None
+            dL_dpose = torch.empty((3, 4), dtype=torch.float32, device=dev) if pose_Rt is not None else None
+            rc = L.gs2d_backward_posed(
                 P, int(degree), M, int(R), _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(sc_),
                 float(scale_modifier), _ptr(rot_), _ptr(tm_), _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx),
                 float(tan_fovy), radii_.data_ptr(), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
                 dc_.data_ptr(), do_.data_ptr(), dL_dmeans2D.data_ptr(), dL_dnormal.data_ptr(), dL_dopacity.data_ptr(),
                 dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dtransMat.data_ptr(), _ptr(dL_dsh),
-                dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(use_sa)), int(bool(debug)), _stream_ptr(dev))
+                dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(use_sa)), int(bool(debug)), _ptr(prt_),
+                _ptr(pq_), _ptr(dL_dpose), _stream_ptr(dev))
         if rc < 0:
             raise RuntimeError(_lib.last_error())
+        if pose_Rt is not None:
+            return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations,
+                    dL_dpose)
+    elif pose_Rt is not None:
+        return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations,
+                torch.zeros((3, 4), dtype=torch.float32, device=dev))
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
 
 

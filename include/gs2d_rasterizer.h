@@ -99,6 +99,33 @@ int gs2d_backward(
     float* dL_drot,                   /* [P,4] */
     int use_sa, int debug, void* stream);
 
+/*
+ * Tracking-regime variants (no counterpart in the reference's native API -- the reference does
+ * this part in PyTorch, render/__init__.py:31-40): the rigid camera transform is applied INSIDE the preprocess
+ * kernels,  means3D_cam = R x + t,  rotations = standardize(q_cam (x) q)  (pytorch3d quaternion_multiply, real part
+ * first), and the backward additionally returns the pose gradient
+ *     dL_dpose[12] (row-major [dL/dR | dL/dt]),  dL/dR = sum_i g_i (x) x_i,  dL/dt = sum_i g_i,
+ * with dL_dmean3D = R^T g_i and dL_drot mapped back to the untransformed quaternions.
+ * pose_Rt: 12 floats row-major [R | t] (device); pose_quat: q_cam (w,x,y,z) (device).  Both NULL = plain call.
+ * Typical use: identity viewmatrix / projection of the intrinsics only, as the reference's tracking renderer does.
+ */
+int gs2d_forward_posed(
+    gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_alloc_fn binning_alloc, void* binning_user,
+    gs2d_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
+    float scale_modifier, const float* rotations, const float* transMat_precomp, const float* viewmatrix,
+    const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+    float* out_others, int* radii, int use_sa, int debug, const float* pose_Rt, const float* pose_quat, void* stream);
+
+int gs2d_backward_posed(
+    int P, int D, int M, int R, const float* background, int width, int height, const float* means3D, const float* shs,
+    const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+    const float* transMat_precomp, const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+    float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix,
+    const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+    float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot, int use_sa, int debug, const float* pose_Rt,
+    const float* pose_quat, float* dL_dpose /* [12] */, void* stream);
+
 /* present: [P] bytes (0/1). */
 int gs2d_mark_visible(int P, const float* means3D, const float* viewmatrix,
                       const float* projmatrix, uint8_t* present, void* stream);

@@ -191,3 +191,52 @@ def dist2_knn3(points):
     if pts.shape[0]:
         lib().orc_dist2_knn3(C.c_int(pts.shape[0]), _p(pts), _p(out))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Tracking-regime composition (gs2d_forward_posed / gs2d_backward_posed): the reference does this part in PyTorch
+# (render/__init__.py:31-40).  Expression order below is the bit-exact contract with the HIP preprocess kernels.
+def compose_pose(means3D, rotations, pose_Rt, pose_q):
+    """means_cam = R x + t ; rot = standardize(q_cam (x) q)   (float32, fixed association order)."""
+    f = np.float32
+    x, y, z = (means3D[:, i].astype(f) for i in range(3))
+    Rt = np.asarray(pose_Rt, f).reshape(3, 4)
+    cam = np.stack([((Rt[r, 0] * x + Rt[r, 1] * y) + Rt[r, 2] * z) + Rt[r, 3] for r in range(3)], 1).astype(f)
+    aw, ax, ay, az = (f(v) for v in np.asarray(pose_q, f))
+    bw, bx, by, bz = (rotations[:, i].astype(f) for i in range(4))
+    ow = ((aw * bw - ax * bx) - ay * by) - az * bz
+    ox = ((aw * bx + ax * bw) + ay * bz) - az * by
+    oy = ((aw * by - ax * bz) + ay * bw) + az * bx
+    oz = ((aw * bz + ax * by) - ay * bx) + az * bw
+    q = np.stack([ow, ox, oy, oz], 1).astype(f)
+    sign = np.where(q[:, 0] < 0, f(-1), f(1)).astype(f)
+    return cam, (q * sign[:, None]).astype(f), sign
+
+
+def forward_posed(means3D, rotations, pose_Rt, pose_q, *args, **kw):
+    cam, q, sign = compose_pose(_f32(means3D).reshape(-1, 3), _f32(rotations).reshape(-1, 4), pose_Rt, pose_q)
+    st = forward(cam, *args, rotations=q, **kw)
+    st["pose_world_means"] = _f32(means3D).reshape(-1, 3)
+    st["pose_Rt"] = np.asarray(pose_Rt, np.float32).reshape(3, 4)
+    st["pose_q"] = np.asarray(pose_q, np.float32).reshape(4)
+    st["pose_sign"] = sign
+    return st
+
+
+def backward_posed(st, dL_dcolor, dL_dallmap):
+    """Backward of forward_posed: the plain backward in the camera frame, then
+    dL/dR = sum g (x) x, dL/dt = sum g, dL/dx = R^T g, dL/dq = sign * L(q_cam)^T dL/dq'  (double accumulation)."""
+    g = backward(st, dL_dcolor, dL_dallmap)
+    gc = g["dL_dmeans3D"].astype(np.float64)
+    x = st["pose_world_means"].astype(np.float64)
+    Rt = st["pose_Rt"].astype(np.float64)
+    dpose = np.zeros((3, 4))
+    dpose[:, :3] = gc.T @ x
+    dpose[:, 3] = gc.sum(0)
+    g["dL_dpose"] = dpose.astype(np.float32)
+    g["dL_dmeans3D_cam"] = g["dL_dmeans3D"]
+    g["dL_dmeans3D"] = (gc @ Rt[:, :3]).astype(np.float32)
+    aw, ax, ay, az = st["pose_q"].astype(np.float64)
+    Lm = np.array([[aw, -ax, -ay, -az], [ax, aw, -az, ay], [ay, az, aw, -ax], [az, -ay, ax, aw]])
+    g["dL_drotations"] = ((g["dL_drotations"].astype(np.float64) @ Lm) * st["pose_sign"][:, None]).astype(np.float32)
+    return g

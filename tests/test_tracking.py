@@ -1,0 +1,139 @@
+"""Fused tracking-regime path (gs2d_forward_posed / gs2d_backward_posed, gaus_slam_amd/tracking.py):
+CPU pins of the oracle-side composition, GPU parity of the fused kernels against it, and agreement with the
+reference's unfused formulation (transform in PyTorch + autograd, render/__init__.py:31-40)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+
+def _world_scene(P, W, H, seed):
+    """Camera-space scene + a random w2c; Gaussians moved to the world frame so that w2c brings them back."""
+    from gaus_slam_amd.scene_synth import random_w2c
+    sc = util.make_scene(P, W, H, seed=seed, regime="tracking")
+    w2c = random_w2c(np.random.default_rng(seed + 100), max_rot_deg=25.0, max_trans=0.5).double()
+    c2w = torch.inverse(w2c)
+    means_w = (sc["means3D"].double() @ c2w[:3, :3].T + c2w[:3, 3]).float()
+    # world rotation = R_c2w * R_cam  (quaternion of R_c2w times q)
+    from gaus_slam_amd.tracking import matrix_to_quaternion
+    qc = matrix_to_quaternion(c2w[:3, :3].float()).double()
+    q = sc["rotations"].double()
+    aw, ax, ay, az = qc
+    bw, bx, by, bz = q.unbind(1)
+    qw = torch.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                      aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], 1).float()
+    sc = dict(sc)
+    sc["means3D"], sc["rotations"] = means_w.contiguous(), qw.contiguous()
+    return sc, w2c.float()
+
+
+def test_matrix_to_quaternion_roundtrip():
+    from gaus_slam_amd.tracking import matrix_to_quaternion
+    from gaus_slam_amd.scene_synth import random_w2c
+    for seed in range(5):
+        R = random_w2c(np.random.default_rng(seed), max_rot_deg=170.0)[:3, :3]
+        w, x, y, z = matrix_to_quaternion(R).double()
+        R2 = torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                           [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                           [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        assert torch.allclose(R2.float(), R, atol=1e-5) and w >= 0
+
+
+def test_oracle_pose_composition_and_gradient_algebra(oracle):
+    from gaus_slam_amd.tracking import matrix_to_quaternion
+    W, H, P = 96, 64, 150
+    sc, w2c = _world_scene(P, W, H, seed=5)
+    cam = sc["cam"]
+    Rt = w2c[:3, :4].numpy()
+    qc = matrix_to_quaternion(w2c[:3, :3]).numpy()
+    camx, q, sign = oracle.compose_pose(sc["means3D"].numpy(), sc["rotations"].numpy(), Rt, qc)
+    ref = (w2c[:3, :3].double() @ sc["means3D"].double().T + w2c[:3, 3:].double()).T
+    assert np.abs(camx - ref.numpy()).max() < 1e-5 and (q[:, 0] >= 0).all()
+    st = oracle.forward_posed(sc["means3D"].numpy(), sc["rotations"].numpy(), Rt, qc, sc["opacities"].numpy(),
+                              cam.viewmatrix.numpy(), cam.projmatrix.numpy(), cam.campos.numpy(), W, H, cam.tanfovx,
+                              cam.tanfovy, scales=sc["scales"].numpy(), colors_precomp=sc["colors"].numpy(), use_sa=True)
+    dc, da = util.make_upstream_grads(W, H)
+    g = oracle.backward_posed(st, (dc * W * H).numpy(), (da * W * H).numpy())
+    # autograd of x_cam = R x + t with the camera-frame gradient as upstream reproduces dL_dpose / dL_dmeans3D
+    w = w2c.double().clone().requires_grad_(True)
+    x = sc["means3D"].double().clone().requires_grad_(True)
+    xc = (w[:3, :3] @ x.T + w[:3, 3:]).T
+    (xc * torch.from_numpy(g["dL_dmeans3D_cam"]).double()).sum().backward()
+    assert util.grad_err(g["dL_dpose"], w.grad[:3, :4].numpy()) < 1e-5
+    assert util.grad_err(g["dL_dmeans3D"], x.grad.numpy()) < 1e-5
+    assert np.abs(g["dL_dpose"]).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_sa", [True, False])
+def test_posed_kernels_match_oracle(oracle, use_sa):
+    from gaus_slam_amd import rasterizer
+    from gaus_slam_amd.tracking import matrix_to_quaternion
+    W, H, P = 320, 240, 4000
+    sc, w2c = _world_scene(P, W, H, seed=8)
+    cam = sc["cam"]
+    Rt = w2c[:3, :4].contiguous()
+    qc = matrix_to_quaternion(w2c[:3, :3]).contiguous()
+    o = oracle.forward_posed(sc["means3D"].numpy(), sc["rotations"].numpy(), Rt.numpy(), qc.numpy(), sc["opacities"].numpy(),
+                             cam.viewmatrix.numpy(), cam.projmatrix.numpy(), cam.campos.numpy(), W, H, cam.tanfovx,
+                             cam.tanfovy, scales=sc["scales"].numpy(), colors_precomp=sc["colors"].numpy(), use_sa=use_sa)
+    dev = torch.device("cuda")
+    e = torch.empty(0, device=dev)
+    t = lambda a: a.to(dev).contiguous()
+    args = (torch.zeros(3, device=dev), t(sc["means3D"]), t(sc["colors"]), t(sc["opacities"]), t(sc["scales"]),
+            t(sc["rotations"]), 1.0, e, t(cam.viewmatrix), t(cam.projmatrix), cam.tanfovx, cam.tanfovy, H, W, e, 0,
+            t(cam.campos), use_sa, False, False)
+    R, color, allmap, radii, geom, binning, img = rasterizer.rasterize_gaussians(*args, pose_Rt=t(Rt), pose_quat=t(qc))
+    assert R == o["num_rendered"]
+    np.testing.assert_array_equal(radii.cpu().numpy(), o["radii"])  # bit-exact geometry through the fused transform
+    stable = (o["stability"] > 2e-5).reshape(H, W)
+    assert np.abs(color.cpu().numpy() - o["color"])[:, stable].max() <= 1e-4
+    assert np.abs(allmap.cpu().numpy() - o["allmap"])[:, stable].max() <= 1e-4
+    dc, da = util.make_upstream_grads(W, H, channels=(0, 1, 5, 6))
+    dc, da = (dc * W * H).numpy(), (da * W * H).numpy()
+    dc[:, ~stable] = 0; da[:, ~stable] = 0
+    go = oracle.backward_posed(o, dc, da)
+    res = rasterizer.rasterize_gaussians_backward(
+        args[0], args[1], radii, args[2], args[4], args[5], 1.0, e, args[8], args[9], args[10], args[11],
+        torch.from_numpy(dc).to(dev), torch.from_numpy(da).to(dev), e, 0, args[16], geom, R, binning, img, use_sa, False,
+        pose_Rt=t(Rt), pose_quat=t(qc))
+    names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dtransMat", "dL_dsh", "dL_dscales",
+             "dL_drotations", "dL_dpose"]
+    gh = {n: r.cpu().numpy() for n, r in zip(names, res)}
+    for k in ["dL_dpose", "dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dcolors"]:
+        assert util.grad_err(gh[k], go[k].reshape(gh[k].shape)) <= 1e-4, k
+
+
+@pytest.mark.gpu
+def test_render_tracking_matches_unfused_reference_formulation():
+    """Same quantities as render/__init__.py:31-40 computed the reference's way (PyTorch transform + autograd through
+    the plain operator) vs the fused op: images and the pose gradient agree to float32 conditioning."""
+    from gaus_slam_amd import render as gsr, tracking
+    W, H, P = 320, 240, 4000
+    sc, w2c = _world_scene(P, W, H, seed=11)
+    dev = torch.device("cuda")
+    settings = gsr.settings_from_camera(sc["cam"], dev, use_sa=True)
+    p = {k: sc[k].to(dev) for k in ("means3D", "scales", "rotations", "opacities", "colors")}
+    dc, da = util.make_upstream_grads(W, H, channels=(0, 1))
+    dc, da = (dc * W * H).to(dev), (da * W * H).to(dev)
+    # fused
+    wf = w2c.to(dev).clone().requires_grad_(True)
+    pkg = tracking.render_tracking(settings, wf, p["means3D"], p["opacities"], p["colors"], p["scales"], p["rotations"])
+    torch.autograd.backward([pkg["render_color"], pkg["allmap"]], [dc, da])
+    # unfused (reference formulation)
+    wu = w2c.to(dev).clone().requires_grad_(True)
+    means_cam = (wu[:3, :3] @ p["means3D"].T + wu[:3, 3:]).T
+    qc = tracking.matrix_to_quaternion(wu[:3, :3].detach())
+    aw, ax, ay, az = qc
+    bw, bx, by, bz = p["rotations"].unbind(1)
+    rot = torch.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                       aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], 1)
+    m2 = torch.zeros_like(means_cam, requires_grad=True)
+    pk2 = gsr.render(settings, means_cam, m2, p["opacities"], colors_precomp=p["colors"], scales=p["scales"], rotations=rot)
+    torch.autograd.backward([pk2["render_color"], pk2["allmap"]], [dc, da])
+    # images: identical except where the ulp-different transform flips a discrete decision
+    diff = (pkg["render_color"] - pk2["render_color"]).abs().amax(0)
+    assert float((diff > 1e-4).float().mean()) < 5e-3
+    assert util.grad_err(wf.grad.cpu().numpy()[:3], wu.grad.cpu().numpy()[:3]) < 2e-3
+    assert float(wf.grad[3].abs().max()) == 0
