@@ -32,7 +32,8 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 __device__ __forceinline__ float fast_exp_neg_half(float r) { return __builtin_amdgcn_exp2f(r * -0.72134752044448170368f); }
 __device__ __forceinline__ float fast_exp_neg_quarter(float q) { return __builtin_amdgcn_exp2f(q * -0.36067376022224085184f); }
 
-// Conservative test "can this splat reach alpha >= 1/255 on any pixel of the rectangle [x0,x1] x [y0,y1]?",
+// Conservative test "can this splat reach alpha >= 1/255 on any pixel of a pixel rectangle?", applied to the four
+// 4x4 sub-blocks of a wave's 8x8 quadrant,
 // evaluated by the lane that holds the splat record.  rho_max = 2 ln(255 opacity) (+margin, precomputed by the
 // preprocess kernel):   alpha >= 1/255  <=>  min(rho3d, rho2d) <= rho_max.
 //  (1) {rho2d <= rho_max} is a disc of radius sqrt(rho_max/100) px around the stored centre.
@@ -46,29 +47,35 @@ __device__ __forceinline__ float fast_exp_neg_quarter(float q) { return __builti
 //      where F is a 1-D parabola.  The splat is dropped only if that minimum exceeds a rounding margin.
 // Anything that cannot be bounded safely is kept.  Culling therefore never changes a result: a culled pair is one
 // the reference would have `continue`d past (tests: bit-exact n_contrib on a stress scene).
-__device__ __forceinline__ bool splat_may_touch(const float4 q0, const float4 q1, const float4 q2, float rho_max,
-                                                float x0, float x1, float y0, float y1)
+// Returns a 4-bit mask: bit r set = the splat may reach alpha >= 1/255 on 4x4 sub-block r of the 8x8 quadrant whose
+// first pixel is (qx, qy)  (sub-block r covers x in [qx + 4(r&1), +3], y in [qy + 4(r>>1), +3]).
+__device__ __forceinline__ uint32_t splat_touch_mask(const float4 q0, const float4 q1, const float4 q2, float rho_max,
+                                                     float qx, float qy)
 {
-    if (!(rho_max >= 0.f)) return false;  // opacity*G can never reach 1/255 (NaN opacity is encoded as +huge)
+    if (!(rho_max >= 0.f)) return 0u;  // opacity*G can never reach 1/255 (NaN opacity is encoded as +huge)
+    const float x0 = qx, x1 = qx + 7.f, y0 = qy, y1 = qy + 7.f;
     const float rl = fast_sqrt(rho_max * (1.0f / GS2D_FILTER_INV_SQ)) + 0.5f;  // cull-only math: hardware sqrt/rcp, margins cover the ulps
-    const bool lowpass_near = !(q0.w + rl < x0 || q0.w - rl > x1 || q1.w + rl < y0 || q1.w - rl > y1);
+    // low-pass disc {rho2d <= rho_max}: bounding box of the disc per sub-block
+    uint32_t lp = 0u;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float sx0 = qx + 4.f * (r & 1), sy0 = qy + 4.f * (r >> 1);
+        if (!(q0.w + rl < sx0 || q0.w - rl > sx0 + 3.f || q1.w + rl < sy0 || q1.w - rl > sy0 + 3.f)) lp |= 1u << r;
+    }
     const float a = rho_max * (q2.x * q2.x + q2.y * q2.y), zz = q2.z * q2.z;
-    if (!(a <= 0.9f * zz) || !(q2.z > 0.f)) return true;  // disc not safely in front of the eye: no bound
+    if (!(a <= 0.9f * zz) || !(q2.z > 0.f)) return 0xFu;  // disc not safely in front of the eye: no bound
     const float inv = fast_rcp(a - zz);
     const float f0 = rho_max * inv, f2 = -inv;
     const float cx = f0 * (q0.x * q2.x + q0.y * q2.y) + f2 * (q0.z * q2.z);
     const float cy = f0 * (q1.x * q2.x + q1.y * q2.y) + f2 * (q1.z * q2.z);
     const float hx = cx * cx - (f0 * (q0.x * q0.x + q0.y * q0.y) + f2 * (q0.z * q0.z));
     const float hy = cy * cy - (f0 * (q1.x * q1.x + q1.y * q1.y) + f2 * (q1.z * q1.z));
-    if (!(hx == hx) || !(hy == hy)) return true;
+    if (!(hx == hx) || !(hy == hy)) return 0xFu;
     const float ex = fast_sqrt(fmaxf(hx, 0.f)), ey = fast_sqrt(fmaxf(hy, 0.f));
     const float mx = 0.5f + 0.02f * ex + 1e-4f * fabsf(cx), my = 0.5f + 0.02f * ey + 1e-4f * fabsf(cy);
-    if (cx + ex + mx < x0 || cx - ex - mx > x1 || cy + ey + my < y0 || cy - ey - my > y1) return lowpass_near;
-    if (lowpass_near) return true;
-    // ellipse centre inside (or within the margin of) the rectangle: certainly touching
-    if (!(cx + mx < x0 || cx - mx > x1 || cy + my < y0 || cy - my > y1)) return true;
-    // exact conic vs rectangle, in coordinates local to the rectangle centre (well conditioned)
-    const float xm = 0.5f * (x0 + x1), ym = 0.5f * (y0 + y1), hw = 0.5f * (x1 - x0), hh = 0.5f * (y1 - y0);
+    if (cx + ex + mx < x0 || cx - ex - mx > x1 || cy + ey + my < y0 || cy - ey - my > y1) return lp;  // AABB misses the quadrant
+    // exact conic in coordinates local to the quadrant centre (|dx|,|dy| <= 3.5: well conditioned)
+    const float xm = qx + 3.5f, ym = qy + 3.5f;
     const float k0 = fmaf(xm, q2.x, -q0.x), k1 = fmaf(xm, q2.y, -q0.y), k2 = fmaf(xm, q2.z, -q0.z);
     const float l0 = fmaf(ym, q2.x, -q1.x), l1 = fmaf(ym, q2.y, -q1.y), l2 = fmaf(ym, q2.z, -q1.z);
     const float Cx = k1 * l2 - k2 * l1, Cy = k2 * l0 - k0 * l2, Cz = k0 * l1 - k1 * l0;          // k x l
@@ -79,25 +86,41 @@ __device__ __forceinline__ bool splat_may_touch(const float4 q0, const float4 q1
     const float Fxy = Ax * Bx + Ay * By - c * (Az * Bz);
     const float Fx = Ax * Cx + Ay * Cy - c * (Az * Cz), Fy = Bx * Cx + By * Cy - c * (Bz * Cz);
     const float F0 = Cx * Cx + Cy * Cy - c * (Cz * Cz);
-    if (!(Fxx > 0.f) || !(Fyy > 0.f)) return true;  // not the convex (ellipse) case after rounding: keep
-    // rounding margin: 1e-4 of the largest magnitude the terms of F can reach on the rectangle
-    const float Px = fabsf(Ax) * hw + fabsf(Bx) * hh + fabsf(Cx), Py = fabsf(Ay) * hw + fabsf(By) * hh + fabsf(Cy);
-    const float Pz = fabsf(Az) * hw + fabsf(Bz) * hh + fabsf(Cz);
+    if (!(Fxx > 0.f) || !(Fyy > 0.f)) return 0xFu;  // not the convex (ellipse) case after rounding: keep
+    // rounding margin: 1e-4 of the largest magnitude the terms of F can reach on the quadrant
+    const float Px = (fabsf(Ax) + fabsf(Bx)) * 3.5f + fabsf(Cx), Py = (fabsf(Ay) + fabsf(By)) * 3.5f + fabsf(Cy);
+    const float Pz = (fabsf(Az) + fabsf(Bz)) * 3.5f + fabsf(Cz);
     const float margin = 1e-4f * (Px * Px + Py * Py + c * (Pz * Pz));
     const float iFxx = fast_rcp(Fxx), iFyy = fast_rcp(Fyy);
-    float fmin_edges = 3.0e38f;
+    uint32_t m = lp;
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
-        const float dy = e ? hh : -hh;  // horizontal edges: F(t, dy) = Fxx t^2 + 2 b t + cq
-        const float b = fmaf(Fxy, dy, Fx), cq = fmaf(fmaf(Fyy, dy, 2.f * Fy), dy, F0);
-        const float t = fminf(fmaxf(-b * iFxx, -hw), hw);
-        fmin_edges = fminf(fmin_edges, fmaf(fmaf(Fxx, t, 2.f * b), t, cq));
-        const float dx = e ? hw : -hw;  // vertical edges: F(dx, t) = Fyy t^2 + 2 b2 t + cq2
-        const float b2 = fmaf(Fxy, dx, Fy), cq2 = fmaf(fmaf(Fxx, dx, 2.f * Fx), dx, F0);
-        const float t2 = fminf(fmaxf(-b2 * iFyy, -hh), hh);
-        fmin_edges = fminf(fmin_edges, fmaf(fmaf(Fyy, t2, 2.f * b2), t2, cq2));
+    for (int r = 0; r < 4; r++) {
+        // sub-block r in local coordinates: dx in [xa, xa+3], dy in [ya, ya+3]
+        const float xa = (r & 1) ? 0.5f : -3.5f, ya = (r >> 1) ? 0.5f : -3.5f;
+        const float xb = xa + 3.f, yb = ya + 3.f;
+        const float sx0 = qx + 4.f * (r & 1), sy0 = qy + 4.f * (r >> 1);
+        // AABB of the ellipse vs the sub-block
+        if (cx + ex + mx < sx0 || cx - ex - mx > sx0 + 3.f || cy + ey + my < sy0 || cy - ey - my > sy0 + 3.f) continue;
+        // ellipse centre inside (or within the margin of) the sub-block: certainly touching
+        bool t = !(cx + mx < sx0 || cx - mx > sx0 + 3.f || cy + my < sy0 || cy - my > sy0 + 3.f);
+        if (!t) {
+            float fmin_edges = 3.0e38f;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const float dy = e ? yb : ya;  // horizontal edges: F(t, dy) = Fxx t^2 + 2 b t + cq
+                const float bq = fmaf(Fxy, dy, Fx), cq = fmaf(fmaf(Fyy, dy, 2.f * Fy), dy, F0);
+                const float tt = fminf(fmaxf(-bq * iFxx, xa), xb);
+                fmin_edges = fminf(fmin_edges, fmaf(fmaf(Fxx, tt, 2.f * bq), tt, cq));
+                const float dx = e ? xb : xa;  // vertical edges: F(dx, t) = Fyy t^2 + 2 b2 t + cq2
+                const float b2 = fmaf(Fxy, dx, Fy), cq2 = fmaf(fmaf(Fxx, dx, 2.f * Fx), dx, F0);
+                const float t2 = fminf(fmaxf(-b2 * iFyy, ya), yb);
+                fmin_edges = fminf(fmin_edges, fmaf(fmaf(Fyy, t2, 2.f * b2), t2, cq2));
+            }
+            t = !(fmin_edges > margin);  // NaN -> keep
+        }
+        if (t) m |= 1u << r;
     }
-    return !(fmin_edges > margin);  // NaN -> keep
+    return m;
 }
 
 // Part A of the per-(pixel, splat) work: ray-splat intersection and alpha (forward.cu:360-387; FMA form identical
@@ -137,11 +160,33 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 // ------------------------------------------------------------------------------------------- forward
-// One wave per 8x8 pixel quadrant, 4 independent waves per 16x16 tile.  Each lane fetches ONE splat record of the
-// current 64-splat batch, tests it against the quadrant, and stages it in wave-private LDS; the wave then walks
-// the set bits of the cull mask reading record j back as a same-address broadcast (5 x ds_read_b128, software-
-// pipelined one splat ahead).  The VALU only does per-pixel math: v_readlane broadcasts cost ~6 SIMD cycles each
-// on gfx950 and drag v_movs behind them (one-SGPR-per-VALU-op limit); LDS broadcasts cost the VALU nothing.
+// One wave per 8x8 pixel quadrant, 4 independent waves per 16x16 tile; inside the wave each 16-lane DPP row owns
+// one 4x4 sub-block.  Per 64-splat batch: lane i fetches record i, tests it against the four sub-blocks
+// (splat_touch_mask) and stages it in wave-private LDS; the four ballots of the mask bits are four depth-ordered
+// QUEUES, one per sub-block.  Every loop trip row r pops the next splat of ITS queue and reads that record from LDS
+// (per-row address, 5 x ds_read_b128, software-pipelined one trip ahead), so the four rows composite four different
+// splats at once: per-pixel order is untouched (a splat that touches several sub-blocks sits in several queues), the
+// trip count is the LONGEST queue instead of the whole list, and the VALU executes only per-pixel math.
+__device__ __forceinline__ int row_select(int row, int j0, int j1, int j2, int j3)
+{
+    return row == 0 ? j0 : (row == 1 ? j1 : (row == 2 ? j2 : j3));
+}
+// pops the lowest set bit of a queue; 64 = empty
+__device__ __forceinline__ int pop_front(uint64_t& m)
+{
+    const int j = m ? __builtin_ctzll(m) : 64;
+    m &= m - 1;  // no-op on 0
+    return j;
+}
+// pops the highest set bit (back-to-front walks); 64 = empty
+__device__ __forceinline__ int pop_back(uint64_t& m)
+{
+    if (!m) return 64;
+    const int j = 63 - __builtin_clzll(m);
+    m &= ~(1ull << j);
+    return j;
+}
+
 template <bool USE_SA>
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -154,10 +199,11 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     WaveBatch& wb = batches[wave];
     const int qx0 = tx * GS2D_TILE + (wave & 1) * 8, qy0 = ty * GS2D_TILE + (wave >> 1) * 8;
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const int row = lane >> 4, li = lane & 15;                       // DPP row = 4x4 sub-block
+    const int lx = (row & 1) * 4 + (li & 3), ly = (row >> 1) * 4 + (li >> 2);  // position inside the quadrant
+    const int px = qx0 + lx, py = qy0 + ly;
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    const float fx0 = (float)qx0, fx1 = (float)(qx0 + 7), fy0 = (float)qy0, fy1 = (float)(qy0 + 7);
     const uint2 range = ranges[tile];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
@@ -170,36 +216,39 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     for (uint32_t base = range.x; base < range.y; base += 64) {
         if (__ballot(!done) == 0) break;
         const int n = min(64, (int)(range.y - base));
-        bool touch = false;
+        uint32_t tm = 0u;
         wave_lds_sync();  // previous batch fully consumed before it is overwritten
         if (lane < n) {
             const uint32_t id = point_list[base + lane];
             const float4* rp = rec + (size_t)id * GS2D_REC_F4;
             const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4];
-            touch = splat_may_touch(r0, r1, r2, r4.z, fx0, fx1, fy0, fy1);
+            tm = splat_touch_mask(r0, r1, r2, r4.z, (float)qx0, (float)qy0);
             wb.q[0][lane] = r0; wb.q[1][lane] = r1; wb.q[2][lane] = r2; wb.q[3][lane] = r3; wb.q[4][lane] = r4;
         }
         wave_lds_sync();
-        uint64_t mask = __ballot(touch);
-        if (mask == 0) continue;
-        // software pipeline: the record of the NEXT surviving splat is fetched from LDS while the current one is
-        // evaluated, so the ds_read latency never sits on the critical path.  The loop is unrolled by two with the
-        // two register sets swapping roles (no c <- n copies: 20 v_movs per splat otherwise).
-        int j = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        float4 a0 = wb.q[0][j], a1 = wb.q[1][j], a2 = wb.q[2][j], a3 = wb.q[3][j], a4 = wb.q[4][j];
+        uint64_t m0 = __ballot(tm & 1u), m1 = __ballot(tm & 2u), m2 = __ballot(tm & 4u), m3 = __ballot(tm & 8u);
+        if ((m0 | m1 | m2 | m3) == 0) continue;
+        // software pipeline: the records of the NEXT trip are fetched from LDS while the current ones are evaluated;
+        // unrolled by two with the two register sets swapping roles (no copies).
+        int j;
+        {
+            const int j0 = pop_front(m0), j1 = pop_front(m1), j2 = pop_front(m2), j3 = pop_front(m3);
+            j = row_select(row, j0, j1, j2, j3);
+        }
+        float4 a0 = wb.q[0][j & 63], a1 = wb.q[1][j & 63], a2 = wb.q[2][j & 63], a3 = wb.q[3][j & 63], a4 = wb.q[4][j & 63];
         float4 b0, b1, b2, b3, b4;
 #define GS2D_FWD_STEP(C0, C1, C2, C3, C4, N0_, N1_, N2_, N3_, N4_)                                                   \
         {                                                                                                            \
-            const bool more = mask != 0;                                                                             \
-            const int jn = more ? __builtin_ctzll(mask) : j;                                                         \
-            mask &= mask - 1; /* no-op when mask == 0 */                                                             \
-            N0_ = wb.q[0][jn]; N1_ = wb.q[1][jn]; N2_ = wb.q[2][jn]; N3_ = wb.q[3][jn]; N4_ = wb.q[4][jn];           \
+            const bool more = (m0 | m1 | m2 | m3) != 0;                                                              \
+            const int j0 = pop_front(m0), j1 = pop_front(m1), j2 = pop_front(m2), j3 = pop_front(m3);                \
+            const int jn = row_select(row, j0, j1, j2, j3);                                                          \
+            N0_ = wb.q[0][jn & 63]; N1_ = wb.q[1][jn & 63]; N2_ = wb.q[2][jn & 63]; N3_ = wb.q[3][jn & 63];          \
+            N4_ = wb.q[4][jn & 63];                                                                                  \
             float alpha, depth;                                                                                      \
             bool ok;                                                                                                 \
             fwd_eval(C0, C1, C2, pxf, pyf, alpha, depth, ok);                                                        \
             const float test_T = T * (1 - alpha);                                                                    \
-            const bool pass = ok && !done;                                                                           \
+            const bool pass = ok && !done && j < 64; /* j == 64: this row's queue is exhausted */                    \
             const bool stop = pass && test_T < 0.0001f;                                                              \
             done = done || stop;                                                                                     \
             if (pass && !stop) {                                                                                     \
@@ -212,7 +261,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                         float exp_std = fmaf(fmaf(-2.0f * Dp, exp_depth, D2), fast_rcp(1 - T), exp_depth * exp_depth); \
                         exp_std = fmaxf(exp_std, 1e-7f);                                                             \
                         const float e = exp_depth - depth;                                                           \
-                        const float conf = fast_exp_neg_quarter((e * e) * fast_rcp(exp_std));                                \
+                        const float conf = fast_exp_neg_quarter((e * e) * fast_rcp(exp_std));                        \
                         depth = fmaf(conf, depth, (1 - conf) * exp_depth);                                           \
                     }                                                                                                \
                     Dp = fmaf(depth, w, Dp);                                                                         \
@@ -341,6 +390,35 @@ __device__ __forceinline__ int reduce16_index(int lane)
     return 8 * ((lane >> 2) & 1) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
 }
 
+// --- the same butterfly inside ONE 16-lane DPP row: 16 values summed over the row's 16 lanes in 45 VALU ops; lane l of
+// every row ends up with value number 8*bit0(l) + 4*bit1(l) + 2*bit2(l) + bit3(l) of ITS row, so the four rows of a wave
+// reduce four different splats at once (scripts/dev/reduce16_row_probe.hip).
+__device__ __forceinline__ float reduce16_row(const float v[16], int lane)
+{
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+    float e[8], f[4], g[2];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = seladd<0x140>(v[2 * i], v[2 * i + 1], b3);  // row_mirror: l <-> 15-l
+#pragma unroll
+    for (int i = 0; i < 4; i++) f[i] = seladd<0x141>(e[2 * i], e[2 * i + 1], b2);  // row_half_mirror: l <-> l^7
+#pragma unroll
+    for (int i = 0; i < 2; i++) g[i] = seladd<0x4E>(f[2 * i], f[2 * i + 1], b1);   // quad_perm [2,3,0,1]
+    return seladd<0xB1>(g[0], g[1], b0);                                            // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ int reduce16_row_index(int lane)
+{
+    return 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+}
+// sum over the 16 lanes of each row, valid in lane 15 of the row (rare low-pass branch)
+__device__ __forceinline__ float row_sum_to_lane15(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    return v;
+}
+
 // Gradient record (GS2D_GRAD_FLOATS = 20 floats per Gaussian):
 //   [0..2] dL_dcolor  [3..5] dL_dnormal  [6..14] dL_dT (Tu,Tv,Tw)  [15] dL_dopacity  [16,17] dL_dmean2D.xy
 //
@@ -361,10 +439,10 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     WaveBatch& wb = batches[wave];
     const int qx0 = tx * GS2D_TILE + (wave & 1) * 8, qy0 = ty * GS2D_TILE + (wave >> 1) * 8;
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const int row = lane >> 4, li = lane & 15;                       // DPP row = 4x4 sub-block (same mapping as the forward)
+    const int px = qx0 + (row & 1) * 4 + (li & 3), py = qy0 + (row >> 1) * 4 + (li >> 2);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    const float fx0 = (float)qx0, fx1 = (float)(qx0 + 7), fy0 = (float)qy0, fy1 = (float)(qy0 + 7);
     const uint2 range = ranges[tile];
     const size_t HW = (size_t)H * W;
     const size_t pix = (size_t)W * py + px;
@@ -403,8 +481,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     for (int d = 32; d >= 1; d >>= 1) max_last = max(max_last, (uint32_t)__shfl_xor((int)max_last, d, 64));
     max_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_last);
 
-    const int ridx = reduce16_index(lane);
-    const bool writer = (lane & 3) == 0;
+    const int ridx = reduce16_row_index(lane);
     // Wave-uniform data-dependent shortcut: when no pixel of this quadrant carries an upstream gradient on the
     // normal channels (SLAM's losses never touch them unless use_normal_loss), everything that only feeds
     // dL_dnormal / the normal term of dL_dalpha is exactly zero and is skipped.  Results are unchanged.
@@ -413,35 +490,36 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     for (int b = nbatches - 1; b >= 0; b--) {
         const uint32_t b0 = (uint32_t)b * 64;
         const int n = (int)min(64u, max_last - b0);
-        bool touch = false;
+        uint32_t tm = 0u;
         wave_lds_sync();  // previous batch fully consumed before it is overwritten
         if (lane < n) {
             const uint32_t my_id = point_list[range.x + b0 + lane];
             const float4* rp = rec + (size_t)my_id * GS2D_REC_F4;
             const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
             float4 r4 = rp[4];
-            touch = splat_may_touch(r0, r1, r2, r4.z, fx0, fx1, fy0, fy1);
+            tm = splat_touch_mask(r0, r1, r2, r4.z, (float)qx0, (float)qy0);
             r4.w = __uint_as_float(my_id);  // the Gaussian id rides in the unused slot of the staged record
             wb.q[0][lane] = r0; wb.q[1][lane] = r1; wb.q[2][lane] = r2; wb.q[3][lane] = r3; wb.q[4][lane] = r4;
         }
         wave_lds_sync();
-        uint64_t mask = __ballot(touch);
-        if (mask == 0) continue;
-        // back to front; geometry of the next surviving splat is prefetched from LDS during the current one.
-        // Unrolled by two with the two geometry register sets swapping roles (no c <- n copies).
-        int j = 63 - __builtin_clzll(mask);
-        mask &= ~(1ull << j);
-        float4 ga0 = wb.q[0][j], ga1 = wb.q[1][j], ga2 = wb.q[2][j];
+        // four depth-ordered queues, one per 4x4 sub-block (= DPP row), walked back to front
+        uint64_t m0 = __ballot(tm & 1u), m1 = __ballot(tm & 2u), m2 = __ballot(tm & 4u), m3 = __ballot(tm & 8u);
+        if ((m0 | m1 | m2 | m3) == 0) continue;
+        int j;
+        {
+            const int j0 = pop_back(m0), j1 = pop_back(m1), j2 = pop_back(m2), j3 = pop_back(m3);
+            j = row_select(row, j0, j1, j2, j3);
+        }
+        float4 ga0 = wb.q[0][j & 63], ga1 = wb.q[1][j & 63], ga2 = wb.q[2][j & 63];
         float4 gb0, gb1, gb2;
 #define GS2D_BWD_STEP(G0, G1, G2, N0_, N1_, N2_)                                                                      \
         {                                                                                                             \
-            const bool more = mask != 0;                                                                              \
-            const int jn = more ? 63 - __builtin_clzll(mask) : j;                                                     \
-            mask &= ~(1ull << jn);                                                                                    \
-            N0_ = wb.q[0][jn]; N1_ = wb.q[1][jn]; N2_ = wb.q[2][jn];                                                  \
-            const float4 c3 = wb.q[3][j], c4 = wb.q[4][j];                                                            \
+            const bool more = (m0 | m1 | m2 | m3) != 0;                                                               \
+            const int jn = row_select(row, pop_back(m0), pop_back(m1), pop_back(m2), pop_back(m3));                   \
+            N0_ = wb.q[0][jn & 63]; N1_ = wb.q[1][jn & 63]; N2_ = wb.q[2][jn & 63];                                   \
+            const float4 c3 = wb.q[3][j & 63], c4 = wb.q[4][j & 63];                                                  \
             const uint32_t contributor = b0 + (uint32_t)j; /* 0-based, as in backward.cu:285 */                       \
-            bool active = inside && contributor < last_contributor;                                                   \
+            bool active = inside && j < 64 && contributor < last_contributor; /* j == 64: row queue exhausted */      \
             if (__ballot(active) != 0) {                                                                              \
                 /* Part A (all lanes): same geometry / alpha as the forward */                                        \
                 const float k0 = fmaf(pxf, G2.x, -G0.x), k1 = fmaf(pxf, G2.y, -G0.y), k2 = fmaf(pxf, G2.z, -G0.z);    \
@@ -542,13 +620,14 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                     g[13] = fmaf(pxf, dk1, fmaf(pyf, dl1, d_zr * s1));                                                \
                     g[14] = fmaf(pxf, dk2, fmaf(pyf, dl2, d_zr)) + d_zl;                                              \
                     g[15] = d_op;                                                                                     \
+                    /* each row reduces ITS splat; one atomic instruction then adds 4 x 64 contiguous bytes */        \
                     float* dst = grad_rec + (size_t)__float_as_uint(c4.w) * GS2D_GRAD_FLOATS;                         \
-                    const float tot = reduce16(g, lane);                                                              \
-                    if (writer) atomicAdd(dst + ridx, tot);                                                           \
+                    const float tot = reduce16_row(g, lane);                                                          \
+                    if (tot != 0.f) atomicAdd(dst + ridx, tot); /* rows without a contributing lane sum to +0 */      \
                     if (__ballot(d_t != 0.f) != 0) {                                                                  \
-                        const float g_mx = wave_sum_to_lane63(d_t * d0);                                              \
-                        const float g_my = wave_sum_to_lane63(d_t * d1);                                              \
-                        if (lane == 63) { atomicAdd(dst + 16, g_mx); atomicAdd(dst + 17, g_my); }                     \
+                        const float g_mx = row_sum_to_lane15(d_t * d0);                                               \
+                        const float g_my = row_sum_to_lane15(d_t * d1);                                               \
+                        if (li == 15 && (g_mx != 0.f || g_my != 0.f)) { atomicAdd(dst + 16, g_mx); atomicAdd(dst + 17, g_my); } \
                     }                                                                                                 \
                 }                                                                                                     \
             }                                                                                                         \
