@@ -250,3 +250,28 @@ def test_replica_shaped_1200x680(oracle):
     for k in ["dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations"]:
         assert util.grad_err(gh[k], go[k].reshape(gh[k].shape)) <= GRAD_TOL, k
     oracle.set_threads(1)
+
+
+def test_scannetpp_shaped_1168x876_2M(oracle):
+    """BASELINE.json configs[4] shape: 1168x876 (73x55 = 4015 tiles, 12 tile-id bits), 2M surfels.  Forward indices
+    bit-exact, images within tolerance on stable pixels; gradients on the parameters the mapping loss touches."""
+    P, W, H = 2000000, 1168, 876
+    sc = util.make_scene(P, W, H, seed=6, regime="mapping")
+    oracle.set_threads(os.cpu_count() or 1)
+    o = util.oracle_forward(oracle, sc, use_sa=True)
+    h = util.hip_forward(sc, use_sa=True)
+    assert h["num_rendered"] == o["num_rendered"] and o["nbits"] == 32 + 12
+    np.testing.assert_array_equal(h["point_list"], o["point_list"])
+    np.testing.assert_array_equal(h["ranges"], o["ranges"])
+    stable = (o["stability"] > KNIFE).reshape(H, W)
+    assert (~stable).mean() < 5e-3
+    assert np.abs(h["color"] - o["color"])[:, stable].max() <= IMG_TOL
+    assert np.abs(h["allmap"] - o["allmap"])[:, stable].max() <= IMG_TOL
+    dc, da = util.make_upstream_grads(W, H, channels=(0, 1, 6))
+    dc, da = (dc * W * H).numpy(), (da * W * H).numpy()
+    dc[:, ~stable] = 0; da[:, ~stable] = 0
+    go = oracle.backward(o, dc, da)
+    gh = util.hip_backward(h, dc, da)
+    for k in ["dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations"]:
+        assert util.grad_err(gh[k], go[k].reshape(gh[k].shape)) <= GRAD_TOL, k
+    oracle.set_threads(1)
