@@ -467,6 +467,11 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         final_D = pix_state[PS_M1 * plane + si];
         final_D2 = pix_state[PS_M2 * plane + si];
     }
+    // Every gradient this wave produces is linear in its pixels' upstream gradients: a quadrant whose 64 pixels all
+    // carry exact zeros (masked-out regions of the SLAM losses) contributes exactly nothing.
+    if (__ballot(dpx0 != 0.f || dpx1 != 0.f || dpx2 != 0.f || dL_ddepth != 0.f || dL_daccum != 0.f || dn0 != 0.f ||
+                 dn1 != 0.f || dn2 != 0.f || dL_dmedian_depth != 0.f || dL_dreg != 0.f) == 0)
+        return;
     const float final_A = 1 - T_final;
     const float bg_dot = fmaf(bg[2], dpx2, fmaf(bg[1], dpx1, bg[0] * dpx0));
     const float sa_k = 1.0f / (4 * fmaxf(mstd * (1.0f / (1 - T_final)), 1e-7f));  // per-pixel constant (IEEE, as the oracle)

@@ -20,8 +20,9 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
         return out
     ws = _Chunk(pts.device)
     with torch.cuda.device(pts.device):
-        rc = _lib.lib().sknn_dist2(N, pts.data_ptr(), out.data_ptr(), ws.cb, None,
+        rc = _lib.lib().sknn_dist2(N, pts.data_ptr(), out.data_ptr(), ws.cb, ws.user,
                                    C.c_void_p(torch.cuda.current_stream(pts.device).cuda_stream))
+    ws.release()
     if rc < 0:
         raise RuntimeError("sknn_dist2 failed: " + _lib.last_error())
     return out

@@ -36,17 +36,33 @@ def _f32c(t):
 
 
 class _Chunk:
-    """Allocator callback target: the C side asks for N bytes, we hand out a torch uint8 tensor
-    (the resizeFunctional lambda of rasterize_points.cu:31-37)."""
+    """Allocator callback target: the C side asks for N bytes, we hand out a torch uint8 tensor (the resizeFunctional
+    lambda of rasterize_points.cu:31-37).  ONE ctypes callback exists per process (creating CFUNCTYPE objects per call
+    costs tens of microseconds); the `user` pointer the C side passes back selects the live _Chunk."""
+
+    _live = {}
+    _next = [1]
 
     def __init__(self, device):
         self.device = device
         self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
-        self.cb = _lib.ALLOC_FN(self._alloc)
+        self.key = _Chunk._next[0]
+        _Chunk._next[0] += 1
+        _Chunk._live[self.key] = self
+        self.cb = _CHUNK_CB
+        self.user = C.c_void_p(self.key)
 
-    def _alloc(self, _user, nbytes):
-        self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-        return self.tensor.data_ptr()
+    def release(self):
+        _Chunk._live.pop(self.key, None)
+
+
+def _chunk_alloc(user, nbytes):
+    ch = _Chunk._live[int(user)]
+    ch.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=ch.device)
+    return ch.tensor.data_ptr()
+
+
+_CHUNK_CB = _lib.ALLOC_FN(_chunk_alloc)
 
 
 def _stream_ptr(device):
@@ -85,11 +101,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             prt_ = _f32c(pose_Rt) if pose_Rt is not None else None
             pq_ = _f32c(pose_quat) if pose_quat is not None else None
             rendered = L.gs2d_forward_posed(
-                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg_), W, H, _ptr(m3_),
+                geom.cb, geom.user, binning.cb, binning.user, img.cb, img.user, P, int(degree), M, _ptr(bg_), W, H, _ptr(m3_),
                 _ptr(sh_), _ptr(col_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(tm_), _ptr(vm_),
                 _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), out_color.data_ptr(),
                 out_others.data_ptr(), radii.data_ptr(), int(bool(use_sa)), int(bool(debug)), _ptr(prt_), _ptr(pq_),
                 _stream_ptr(dev))
+        for ch in (geom, binning, img):
+            ch.release()
         if rendered < 0:
             raise RuntimeError(_lib.last_error())
     return rendered, out_color, out_others, radii, geom.tensor, binning.tensor, img.tensor

@@ -275,3 +275,24 @@ def test_scannetpp_shaped_1168x876_2M(oracle):
     for k in ["dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations"]:
         assert util.grad_err(gh[k], go[k].reshape(gh[k].shape)) <= GRAD_TOL, k
     oracle.set_threads(1)
+
+
+def test_masked_upstream_gradients(oracle):
+    """Upstream gradients that are exactly zero on most of the image (SLAM's masked losses): the backward's
+    zero-quadrant early exit must not change any gradient."""
+    W, H, P = 320, 240, 6000
+    sc = util.make_scene(P, W, H, seed=17, regime="mapping")
+    o = util.oracle_forward(oracle, sc, use_sa=True)
+    h = util.hip_forward(sc, use_sa=True)
+    stable = (o["stability"] > KNIFE).reshape(H, W)
+    dc, da = util.make_upstream_grads(W, H, channels=(0, 1, 6))
+    dc, da = (dc * W * H).numpy(), (da * W * H).numpy()
+    mask = np.zeros((H, W), bool)
+    mask[60:150, 100:260] = True      # only a window carries gradient; cuts through tiles and quadrants
+    mask[::7, ::5] |= True            # plus isolated pixels
+    mask &= stable
+    dc[:, ~mask] = 0; da[:, ~mask] = 0
+    go = oracle.backward(o, dc, da)
+    gh = util.hip_backward(h, dc, da)
+    for k in ["dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dtransMat", "dL_dmeans2D"]:
+        assert util.grad_err(gh[k], go[k].reshape(gh[k].shape)) <= GRAD_TOL, k
