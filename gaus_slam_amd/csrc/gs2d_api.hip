@@ -126,7 +126,7 @@ void gs2d_geometry_layout(int P, size_t o[5])
 void gs2d_binning_layout(int R, size_t o[2])
 {
     const BinLayout L = bin_layout(R);
-    o[0] = L.point_list; o[1] = L.keys;
+    o[0] = L.point_list; o[1] = L.keys;  // (L.hits is internal)
 }
 void gs2d_image_layout(int width, int height, size_t o[2])
 {
@@ -217,6 +217,7 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     char* bin = (char*)binning_alloc(binning_user, BL.total);
     if (!bin) return fail_msg("binning allocation failed");
     uint32_t* point_list = (uint32_t*)(bin + BL.point_list);
+    uint8_t* hits = (uint8_t*)(bin + BL.hits);
     uint64_t* keys = (uint64_t*)(bin + BL.keys);
     uint32_t* vals_alt = (uint32_t*)(bin + BL.vals_alt);
     uint64_t* keys_alt = (uint64_t*)(bin + BL.keys_alt);
@@ -260,7 +261,7 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
         GS2D_STAGE("tile depth sort");
     }
     g_timer.begin(ST_BLEND_FWD, s);
-    gs2d::launch_blend_fwd(width, height, ranges, point_list, rec, background, out_color, out_others, pix_state,
+    gs2d::launch_blend_fwd(width, height, ranges, point_list, rec, background, out_color, out_others, pix_state, hits,
                            use_sa, s);
     g_timer.end(ST_BLEND_FWD, s);
     GS2D_STAGE("blend_fwd");
@@ -305,13 +306,14 @@ int gs2d_backward_posed(int P, int D, int M, int R, const float* background, int
     const uint8_t* clamped = (const uint8_t*)(geom_buffer + GL.clamped);
     float* grad_rec = (float*)(geom_buffer + GL.grad_rec);
     const uint32_t* point_list = (const uint32_t*)(binning_buffer + BL.point_list);
+    const uint8_t* hits = (const uint8_t*)(binning_buffer + BL.hits);
     const uint2* ranges = (const uint2*)(img_buffer + IL.ranges);
     const float* pix_state = (const float*)(img_buffer + IL.pix);
 
     GS2D_CHECK(hipMemsetAsync(grad_rec, 0, sizeof(float) * GS2D_GRAD_FLOATS * (size_t)P, s), "memset grad_rec");
     if (R > 0) {
         g_timer.begin(ST_BLEND_BWD, s);
-        gs2d::launch_blend_bwd(width, height, ranges, point_list, rec, background, pix_state, dL_dpix, dL_depths,
+        gs2d::launch_blend_bwd(width, height, ranges, point_list, rec, background, pix_state, hits, dL_dpix, dL_depths,
                                grad_rec, use_sa, s);
         g_timer.end(ST_BLEND_BWD, s);
         GS2D_STAGE("blend_bwd");

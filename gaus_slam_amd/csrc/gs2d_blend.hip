@@ -191,7 +191,7 @@ template <bool USE_SA>
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
-                 float* __restrict__ out_others, float* __restrict__ pix_state, size_t plane)
+                 float* __restrict__ out_others, float* __restrict__ pix_state, size_t plane, uint8_t* __restrict__ hits)
 {
     __shared__ WaveBatch batches[4];
     const int tile = blockIdx.x;
@@ -223,6 +223,8 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             const float4* rp = rec + (size_t)id * GS2D_REC_F4;
             const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4];
             tm = splat_touch_mask(r0, r1, r2, r4.z, (float)qx0, (float)qy0);
+            // one byte per (instance, quadrant): the backward rebuilds its row queues from these bits, no second cull test
+            hits[(size_t)(base + lane) * 4 + wave] = (uint8_t)tm;
             wb.q[0][lane] = r0; wb.q[1][lane] = r1; wb.q[2][lane] = r2; wb.q[3][lane] = r3; wb.q[4][lane] = r4;
         }
         wave_lds_sync();
@@ -240,8 +242,8 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 #define GS2D_FWD_STEP(C0, C1, C2, C3, C4, N0_, N1_, N2_, N3_, N4_)                                                   \
         {                                                                                                            \
             const bool more = (m0 | m1 | m2 | m3) != 0;                                                              \
-            const int j0 = pop_front(m0), j1 = pop_front(m1), j2 = pop_front(m2), j3 = pop_front(m3);                \
-            const int jn = row_select(row, j0, j1, j2, j3);                                                          \
+            const int nj0 = pop_front(m0), nj1 = pop_front(m1), nj2 = pop_front(m2), nj3 = pop_front(m3);            \
+            const int jn = row_select(row, nj0, nj1, nj2, nj3);                                                      \
             N0_ = wb.q[0][jn & 63]; N1_ = wb.q[1][jn & 63]; N2_ = wb.q[2][jn & 63]; N3_ = wb.q[3][jn & 63];          \
             N4_ = wb.q[4][jn & 63];                                                                                  \
             float alpha, depth;                                                                                      \
@@ -430,8 +432,8 @@ template <bool USE_SA>
 __global__ void __launch_bounds__(256)
 blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ pix_state,
-                 size_t plane, const float* __restrict__ dL_dpix, const float* __restrict__ dL_dothers,
-                 float* __restrict__ grad_rec)
+                 size_t plane, const uint8_t* __restrict__ hits, const float* __restrict__ dL_dpix,
+                 const float* __restrict__ dL_dothers, float* __restrict__ grad_rec)
 {
     __shared__ WaveBatch batches[4];
     const int tile = blockIdx.x;
@@ -502,7 +504,8 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             const float4* rp = rec + (size_t)my_id * GS2D_REC_F4;
             const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
             float4 r4 = rp[4];
-            tm = splat_touch_mask(r0, r1, r2, r4.z, (float)qx0, (float)qy0);
+            // queues come from the cull bits the forward stored for this (instance, quadrant): no second cull test
+            tm = hits[(size_t)(range.x + b0 + lane) * 4 + wave];
             r4.w = __uint_as_float(my_id);  // the Gaussian id rides in the unused slot of the staged record
             wb.q[0][lane] = r0; wb.q[1][lane] = r1; wb.q[2][lane] = r2; wb.q[3][lane] = r3; wb.q[4][lane] = r4;
         }
@@ -652,31 +655,31 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 namespace gs2d {
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
-                      const float* bg, float* out_color, float* out_others, float* pix_state, int use_sa,
+                      const float* bg, float* out_color, float* out_others, float* pix_state, uint8_t* hits, int use_sa,
                       hipStream_t s)
 {
     const int gx = (W + GS2D_TILE - 1) / GS2D_TILE, gy = (H + GS2D_TILE - 1) / GS2D_TILE;
     const size_t plane = (size_t)gx * gy * GS2D_TILE_PIX;
     if (use_sa)
         hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(gx * gy), dim3(256), 0, s, W, H, gx, ranges, point_list, rec,
-                           bg, out_color, out_others, pix_state, plane);
+                           bg, out_color, out_others, pix_state, plane, hits);
     else
         hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(gx * gy), dim3(256), 0, s, W, H, gx, ranges, point_list, rec,
-                           bg, out_color, out_others, pix_state, plane);
+                           bg, out_color, out_others, pix_state, plane, hits);
 }
 
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
-                      const float* bg, const float* pix_state, const float* dL_dpix, const float* dL_dothers,
-                      float* grad_rec, int use_sa, hipStream_t s)
+                      const float* bg, const float* pix_state, const uint8_t* hits, const float* dL_dpix,
+                      const float* dL_dothers, float* grad_rec, int use_sa, hipStream_t s)
 {
     const int gx = (W + GS2D_TILE - 1) / GS2D_TILE, gy = (H + GS2D_TILE - 1) / GS2D_TILE;
     const size_t plane = (size_t)gx * gy * GS2D_TILE_PIX;
     if (use_sa)
         hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(gx * gy), dim3(256), 0, s, W, H, gx, ranges, point_list, rec,
-                           bg, pix_state, plane, dL_dpix, dL_dothers, grad_rec);
+                           bg, pix_state, plane, hits, dL_dpix, dL_dothers, grad_rec);
     else
         hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(gx * gy), dim3(256), 0, s, W, H, gx, ranges, point_list, rec,
-                           bg, pix_state, plane, dL_dpix, dL_dothers, grad_rec);
+                           bg, pix_state, plane, hits, dL_dpix, dL_dothers, grad_rec);
 }
 
 }  // namespace gs2d

@@ -33,7 +33,7 @@ struct GeomLayout {
     size_t depths, tiles_touched, point_offsets, rec, clamped, scan_tmp, grad_rec, total;
 };
 struct BinLayout {
-    size_t point_list, keys, vals_alt, keys_alt, hist, total;
+    size_t point_list, hits, keys, vals_alt, keys_alt, hist, total;
     size_t hist_elems;
 };
 struct ImgLayout {
@@ -70,6 +70,8 @@ static inline BinLayout bin_layout(int R)
     size_t o = 0;
     const size_t r = (size_t)(R > 0 ? R : 1);
     L.point_list = o; o = gs2d_align_up(o + 4 * r, 256);
+    // forward -> backward: per instance and quadrant, the 4-bit sub-block cull mask (one byte each)
+    L.hits = o; o = gs2d_align_up(o + 4 * r, 256);
     L.keys = o; o = gs2d_align_up(o + 8 * r, 256);
     L.vals_alt = o; o = gs2d_align_up(o + 4 * r, 256);
     L.keys_alt = o; o = gs2d_align_up(o + 8 * r, 256);
@@ -137,9 +139,9 @@ void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* key
                             uint32_t* vals_alt, hipStream_t s);
 void launch_tile_ranges(int R, const uint64_t* keys, uint2* ranges, int tiles, hipStream_t s);
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
-                      const float* bg, float* out_color, float* out_others, float* pix_state, int use_sa,
+                      const float* bg, float* out_color, float* out_others, float* pix_state, uint8_t* hits, int use_sa,
                       hipStream_t s);
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
-                      const float* bg, const float* pix_state, const float* dL_dpix, const float* dL_dothers,
-                      float* grad_rec, int use_sa, hipStream_t s);
+                      const float* bg, const float* pix_state, const uint8_t* hits, const float* dL_dpix,
+                      const float* dL_dothers, float* grad_rec, int use_sa, hipStream_t s);
 }  // namespace gs2d
