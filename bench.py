@@ -158,8 +158,22 @@ def main():
                 traffic = json.load(open(tpath)).get(dom)
             except Exception:
                 traffic = None
+        # measured streaming bandwidth of this box (1 GiB device-to-device copy), quoted beside the 8 TB/s spec peak
+        x = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        y = torch.empty_like(x)
+        for _ in range(2):
+            y.copy_(x)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            y.copy_(x)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * x.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del x, y
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "measured_copy_GBps": round(copy_gbs, 1),
                     "kernel_ms": round(stage_ms[dom], 4),
                     "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                     "frame_algorithmic_bytes": 492 * P + 196 * R + 136 * H * W,
@@ -207,7 +221,22 @@ def cpu_baseline_leg(sc, W, H, use_sa):
     for _ in range(reps):
         frame()
     dt = (time.perf_counter() - t0) / reps
+    # BASELINE.json configs[0]: 160x120 / 256 Gaussians forward through the pure-PyTorch CPU path (oracle/torch_ref.py)
+    torch_a = None
+    try:
+        from oracle import torch_ref
+        sa = make_scene(256, 160, 120, seed=0, regime="mapping")
+        ca = sa["cam"]
+        torch.set_num_threads(min(cores, 8))  # thousands of tiny ops: more threads only add synchronisation cost
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            torch_ref.render(sa["means3D"], sa["scales"], sa["rotations"], sa["opacities"], sa["colors"], ca.viewmatrix,
+                             ca.projmatrix, 160, 120, use_sa=use_sa)
+        torch_a = round(time.perf_counter() - t1, 4)
+    except Exception as ex:  # the CPU reference is optional colour, never a reason to fail the bench
+        torch_a = f"failed: {ex}"
     return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "pure_pytorch_cpu_160x120_256_fwd_s": torch_a, "pure_pytorch_threads": min(cores, 8),
             "sample": f"same workload ({W}x{H}, {sc['means3D'].shape[0]} Gaussians), oracle/gs2d_oracle.c fwd+bwd, "
                       f"OpenMP over tiles in the blend stages, 1 warm-up + {reps} timed frames"}
 
