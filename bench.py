@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-sa", action="store_true", help="use_sa=False (SLAM default is True)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--adam", action="store_true", help="also run a (fused, lr=0) Adam step on the 13 floats per Gaussian "
+                    "inside the timed step -- BASELINE.md section 5's BA-step definition; off for the fwd+bwd metric")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a single GPU)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -104,6 +106,17 @@ def main():
 
     ba = ba_shard.KeyframeShardedBA(params, render_fn)
     keyframes = list(range(world))
+    opt = None
+    if args.adam:  # lr = 0: the full moment update runs, the scene (and so num_rendered) stays fixed (eps as scene/Gaussians.py:137)
+        opt = torch.optim.Adam(list(params.values()), lr=0.0, eps=1e-15, fused=True)
+    names = list(ba_shard.BUCKET_FIELDS)
+
+    def one_step():
+        g = ba.step(keyframes)
+        if opt is not None:
+            for n in names:
+                params[n].grad = g[n].reshape(params[n].shape)
+            opt.step()
 
     def sync():
         if world > 1:
@@ -111,11 +124,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        ba.step(keyframes)
+        one_step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ba.step(keyframes)
+        one_step()
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -188,7 +201,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {W}x{H} / {P} Gaussians (BASELINE.md config B), mapping regime, "
                                    f"use_sa={use_sa}, 1 keyframe per GPU", "num_rendered": R, "visible": visible,
-                       "step": "op forward+backward" + (" + all-reduce of the [P,13] grad bucket" if world > 1 else ""),
+                       "step": "op forward+backward" + (" + all-reduce of the [P,13] grad bucket" if world > 1 else "")
+                               + (" + fused Adam (lr=0)" if args.adam else ""),
                        "parallelism": f"keyframe-sharded x{world}"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
