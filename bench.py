@@ -184,9 +184,22 @@ def main():
         torch.cuda.synchronize()
         copy_gbs = 5 * 2 * x.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del x, y
+        # secondary (honest) ceiling: the dominant kernel is VALU-issue bound; instruction counts come from the committed
+        # rocprofv3 PMC summary, the 4-cycles-per-wave64-fp32-instruction peak from scripts/dev/valu_bench.hip
+        valu = None
+        vpath = os.path.join(ROOT, "profiles", "pmc_valu.json")
+        if os.path.exists(vpath) and (P, W, H) == (500000, 640, 480):
+            try:
+                vi = json.load(open(vpath)).get(dom)
+                peak_ginst = 1024 * 2.4 / 4.0  # G wave-instructions/s
+                ach = vi["valu_wave_insts"] / (stage_ms[dom] * 1e-3) / 1e9
+                valu = {"kernel": dom, "achieved_Gwaveinst_s": round(ach, 1), "peak_Gwaveinst_s": peak_ginst,
+                        "frac": round(ach / peak_ginst, 3)}
+            except Exception:
+                valu = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "measured_copy_GBps": round(copy_gbs, 1),
+                    "measured_copy_GBps": round(copy_gbs, 1), "valu_ceiling": valu,
                     "kernel_ms": round(stage_ms[dom], 4),
                     "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                     "frame_algorithmic_bytes": 492 * P + 196 * R + 136 * H * W,
