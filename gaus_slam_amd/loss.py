@@ -1,0 +1,61 @@
+"""Fused post-op + loss for the SLAM iterations.
+
+Equivalent to the reference's default-configuration pipeline between the rasterizer and `loss.backward()`:
+render/__init__.py:46-49 (weight-normalised depth, near/far outliers zeroed) followed by slam/Loss.py:22-58
+(nan_to_num, depth / silhouette masks, masked L1 sums for tracking, masked means + 0.1*dist-style term for mapping).
+One autograd node, two HIP kernels (csrc/gs2d_loss.hip).  Settings outside the default configuration
+(use_normal_loss, ignore_outliners, enable_exposure) are not covered -- use the PyTorch formulation for those."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class _SlamLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, allmap, gt_color, gt_depth, cfg):
+        if not color.is_cuda:
+            raise RuntimeError("color must be a CUDA tensor")
+        dev = color.device
+        H, W = color.shape[1], color.shape[2]
+        color_, allmap_ = color.detach().float().contiguous(), allmap.detach().float().contiguous()
+        gtc = gt_color.detach().float().contiguous().reshape(H, W, 3)
+        gtd = gt_depth.detach().float().contiguous().reshape(H, W)
+        ws = torch.empty(8, dtype=torch.float64, device=dev)
+        out = torch.empty(8, dtype=torch.float32, device=dev)
+        g_color, g_allmap = torch.empty_like(color_), torch.empty_like(allmap_)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gs2d_slam_loss(
+                int(cfg["mode"]), W, H, color_.data_ptr(), allmap_.data_ptr(), gtc.data_ptr(), gtd.data_ptr(),
+                float(cfg["w_color"]), float(cfg["w_depth"]), float(cfg.get("w_dist", 0.0)), float(cfg.get("silmask_th", 0.9)),
+                float(cfg.get("edge_thres", 0.4)), int(bool(cfg.get("use_edge_growth", False))),
+                int(bool(cfg.get("use_weight_norm", True))), float(cfg.get("eps", 1e-6)), float(cfg.get("depth_near", 1e-2)),
+                float(cfg.get("depth_far", 1e2)), ws.data_ptr(), out.data_ptr(), g_color.data_ptr(), g_allmap.data_ptr(),
+                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc < 0:
+            raise RuntimeError("gs2d_slam_loss failed")
+        ctx.save_for_backward(g_color, g_allmap)
+        ctx.terms = out
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        g_color, g_allmap = ctx.saved_tensors
+        return g_color * grad_loss, g_allmap * grad_loss, None, None, None
+
+
+def tracking_loss(color, allmap, gt_color, gt_depth, w_color, w_depth, silmask_th=0.9, use_weight_norm=True, eps=1e-6,
+                  depth_near=1e-2, depth_far=1e2):
+    """slam/Loss.py:35-49 on top of render/__init__.py:46-49: masked (depth-valid & alpha > silmask_th) L1 SUMS."""
+    return _SlamLoss.apply(color, allmap, gt_color, gt_depth, dict(
+        mode=0, w_color=w_color, w_depth=w_depth, silmask_th=silmask_th, use_weight_norm=use_weight_norm, eps=eps,
+        depth_near=depth_near, depth_far=depth_far))
+
+
+def mapping_loss(color, allmap, gt_color, gt_depth, w_color, w_depth, w_dist, use_edge_growth=False, edge_thres=0.4,
+                 use_weight_norm=True, eps=1e-6, depth_near=1e-2, depth_far=1e2):
+    """slam/Loss.py:51-58: masked L1 MEANS for colour / depth plus the mean of render_dist over the colour mask."""
+    return _SlamLoss.apply(color, allmap, gt_color, gt_depth, dict(
+        mode=1, w_color=w_color, w_depth=w_depth, w_dist=w_dist, use_edge_growth=use_edge_growth, edge_thres=edge_thres,
+        use_weight_norm=use_weight_norm, eps=eps, depth_near=depth_near, depth_far=depth_far))

@@ -135,6 +135,20 @@ int gs2d_mark_visible(int P, const float* means3D, const float* viewmatrix,
 int sknn_dist2(int N, const float* points, float* out,
                gs2d_alloc_fn ws_alloc, void* ws_user, void* stream);
 
+/*
+ * Fused post-op + loss of the SLAM iterations (the reference does this in PyTorch:
+ * render/__init__.py:46-49 weight-normalised depth + outlier zeroing, slam/Loss.py:22-58 nan_to_num, masks, masked L1).
+ * mode 0 = tracking (masked sums), 1 = mapping (masked means + dist term).  color [3,H,W], allmap [7,H,W] are the raw
+ * rasterizer outputs, gt_color_hwc [H,W,3], gt_depth [H,W].  Writes loss_out[0] = loss (loss_out[1..5] = colour sum,
+ * depth sum, dist sum, #colour-mask, #depth-mask) and the gradients of the loss w.r.t. color / allmap.
+ * Default-configuration losses only (no normal loss, no outlier rejection, no exposure).
+ */
+int gs2d_slam_loss(int mode, int width, int height, const float* color, const float* allmap, const float* gt_color_hwc,
+                   const float* gt_depth, float w_color, float w_depth, float w_dist, float silmask_th, float edge_thres,
+                   int use_edge_growth, int use_weight_norm, float eps, float depth_near, float depth_far,
+                   double* workspace /* >= 8 doubles */, float* loss_out /* [8] */, float* dL_dcolor, float* dL_dallmap,
+                   void* stream);
+
 /* Sizes of the three scratch chunks (what the allocator callbacks will be asked for). */
 size_t gs2d_geometry_bytes(int P);
 size_t gs2d_image_bytes(int width, int height);
