@@ -52,8 +52,10 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-sa", action="store_true", help="use_sa=False (SLAM default is True)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--adam", action="store_true", help="also run a (fused, lr=0) Adam step on the 13 floats per Gaussian "
-                    "inside the timed step -- BASELINE.md section 5's BA-step definition; off for the fwd+bwd metric")
+    ap.add_argument("--adam", nargs="?", const="fused", default=None, choices=["fused", "torch"],
+                    help="also run a (lr=0) Adam step on the 13 floats per Gaussian inside the timed step -- BASELINE.md "
+                    "section 5's BA-step definition; off for the fwd+bwd metric.  fused = gs2d_adam_step over the flat SoA "
+                    "(one launch), torch = torch.optim.Adam(fused=True) over the five tensors")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a single GPU)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -92,6 +94,11 @@ def main():
         "rotations": sc["rotations"].to(dev).requires_grad_(True),
         "colors": sc["colors"].to(dev).requires_grad_(True),
     }
+    soa = None
+    if args.adam == "fused":  # parameters live in ONE flat buffer in the all-reduce bucket layout (gaus_slam_amd/optim.py)
+        from gaus_slam_amd import optim as gs_optim
+        soa = gs_optim.GaussianSoA(params)
+        params = dict(soa.leaves())
     dcolor, dallmap = make_upstream_grads(W, H, seed=1)
     dcolor, dallmap = dcolor.to(dev), dallmap.to(dev)
     settings = gs_render.settings_from_camera(cam, dev, use_sa=use_sa)
@@ -107,16 +114,23 @@ def main():
     ba = ba_shard.KeyframeShardedBA(params, render_fn)
     keyframes = list(range(world))
     opt = None
-    if args.adam:  # lr = 0: the full moment update runs, the scene (and so num_rendered) stays fixed (eps as scene/Gaussians.py:137)
+    # lr = 0: the full moment update runs, the scene (and so num_rendered) stays fixed (eps as scene/Gaussians.py:137)
+    if args.adam == "torch":
         opt = torch.optim.Adam(list(params.values()), lr=0.0, eps=1e-15, fused=True)
+    elif args.adam == "fused":
+        opt = gs_optim.FusedGaussianAdam(soa, {})
     names = list(ba_shard.BUCKET_FIELDS)
 
     def one_step():
         g = ba.step(keyframes)
-        if opt is not None:
+        if args.adam == "torch":
             for n in names:
                 params[n].grad = g[n].reshape(params[n].shape)
             opt.step()
+        elif args.adam == "fused":
+            if world == 1:  # K=1 bypasses the bucket (bit-for-bit single-GPU path): pack it here
+                ba.bucket.pack(g)
+            opt.step(ba.bucket.flat)
 
     def sync():
         if world > 1:
@@ -215,7 +229,7 @@ def main():
             "config": {"workload": f"synthetic {W}x{H} / {P} Gaussians (BASELINE.md config B), mapping regime, "
                                    f"use_sa={use_sa}, 1 keyframe per GPU", "num_rendered": R, "visible": visible,
                        "step": "op forward+backward" + (" + all-reduce of the [P,13] grad bucket" if world > 1 else "")
-                               + (" + fused Adam (lr=0)" if args.adam else ""),
+                               + (f" + {args.adam} Adam (lr=0)" if args.adam else ""),
                        "parallelism": f"keyframe-sharded x{world}"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -149,6 +149,18 @@ int gs2d_slam_loss(int mode, int width, int height, const float* color, const fl
                    double* workspace /* >= 8 doubles */, float* loss_out /* [8] */, float* dL_dcolor, float* dL_dallmap,
                    void* stream);
 
+/*
+ * Fused dense Adam over the flat Gaussian SoA (the reference: torch.optim.Adam(l, lr=0.0, eps=1e-15)
+ * over five tensors, scene/Gaussians.py:121-137).  param / grad / exp_avg / exp_avg_sq are flat fp32 device buffers of n
+ * elements (16-byte aligned); group g covers elements [group_end[g-1], group_end[g]) and uses learning rate group_lr[g]
+ * (group_end / group_lr are HOST arrays, n_groups <= GS2D_ADAM_MAX_GROUPS, group_end[n_groups-1] == n).  `step` is the
+ * 1-based step count used for the bias corrections.  No weight decay, no amsgrad.
+ */
+#define GS2D_ADAM_MAX_GROUPS 8
+int gs2d_adam_step(int n_groups, const unsigned long long* group_end, const float* group_lr, float beta1, float beta2,
+                   float eps, int step, unsigned long long n, float* param, const float* grad, float* exp_avg,
+                   float* exp_avg_sq, void* stream);
+
 /* Sizes of the three scratch chunks (what the allocator callbacks will be asked for). */
 size_t gs2d_geometry_bytes(int P);
 size_t gs2d_image_bytes(int width, int height);
