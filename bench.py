@@ -111,7 +111,8 @@ def main():
         last["radius"] = pkg["radius"]
         return (pkg["render_color"], pkg["allmap"]), (dcolor, dallmap)
 
-    ba = ba_shard.KeyframeShardedBA(params, render_fn)
+    # gradients are produced directly in the all-reduce bucket whenever the bucket is consumed (N > 1, fused Adam)
+    ba = ba_shard.KeyframeShardedBA(params, render_fn, direct_grads=(world > 1 or args.adam == "fused"))
     keyframes = list(range(world))
     opt = None
     # lr = 0: the full moment update runs, the scene (and so num_rendered) stays fixed (eps as scene/Gaussians.py:137)

@@ -8,6 +8,7 @@ fp32 bucket of 13 floats per Gaussian (xyz 3 | opacity 1 | scaling 2 | rotation 
 scene/Gaussians.py:124-135) and summed with a single all-reduce.  World size 1 skips the collective, so K=1
 reproduces the single-GPU path bit for bit.
 """
+import contextlib
 from collections import OrderedDict
 
 import torch
@@ -36,7 +37,7 @@ class GradBucket:
             g = grads.get(name)
             if g is None:
                 v.zero_()
-            else:
+            elif g.data_ptr() != v.data_ptr():  # already written in place by the rasterizer (direct_grads)
                 v.copy_(g.reshape(v.shape))
 
     def all_reduce(self, group=None, average=False):
@@ -57,7 +58,11 @@ class KeyframeShardedBA:
     render_loss_fn(params, keyframe) -> scalar loss OR (outputs, upstream_grads) pair for torch.autograd.backward.
     """
 
-    def __init__(self, params, render_loss_fn, group=None, average=False):
+    def __init__(self, params, render_loss_fn, group=None, average=False, direct_grads=False):
+        """direct_grads: let the rasterizer's backward write the parameter gradients straight into the bucket (no pack
+        copies).  Safe in every case -- a gradient that did not land in the bucket (the op was not fed the leaf itself,
+        e.g. activations in between) is packed by copy as before."""
+        self.direct_grads = direct_grads
         self.params = params
         self.fn = render_loss_fn
         self.group = group
@@ -73,15 +78,20 @@ class KeyframeShardedBA:
     def rank(self):
         return dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
 
-    def local_backward(self, keyframe):
+    def local_backward(self, keyframe, sink=None):
         for p in self.params.values():
             p.grad = None
         res = self.fn(self.params, keyframe)
-        if isinstance(res, tuple):
-            outs, ups = res
-            torch.autograd.backward(list(outs), list(ups))
-        else:
-            res.backward()
+        ctx = contextlib.nullcontext()
+        if sink is not None:
+            from . import rasterizer
+            ctx = rasterizer.grad_sink(sink)
+        with ctx:
+            if isinstance(res, tuple):
+                outs, ups = res
+                torch.autograd.backward(list(outs), list(ups))
+            else:
+                res.backward()
         return {k: p.grad for k, p in self.params.items()}
 
     def step(self, keyframes):
@@ -90,7 +100,7 @@ class KeyframeShardedBA:
         mine = shard_keyframes(keyframes, self.rank, self.world_size)
         if self.world_size == 1 and len(mine) == 1:
             # degenerate K=1 case == the single-GPU path, bit for bit: no bucket, no copies, no collective
-            g = self.local_backward(mine[0])
+            g = self.local_backward(mine[0], self.bucket.views if self.direct_grads else None)
             return OrderedDict((name, g[name].reshape(v.shape) if g.get(name) is not None else torch.zeros_like(v))
                                for name, v in self.bucket.views.items())
         if not mine:
@@ -98,7 +108,7 @@ class KeyframeShardedBA:
         else:
             acc = None
             for kf in mine:
-                g = self.local_backward(kf)
+                g = self.local_backward(kf, self.bucket.views if (self.direct_grads and acc is None) else None)
                 if acc is None:
                     self.bucket.pack(g)
                     acc = True

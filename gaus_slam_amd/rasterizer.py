@@ -7,6 +7,7 @@ _RasterizeGaussians :44-161) and the pybind functions of RAST/ext.cpp:15-19 / RA
 it runs unchanged on PyTorch-ROCm.  All compute happens in the HIP library behind the C ABI
 (include/gs2d_rasterizer.h); torch only provides device memory and the current stream.
 """
+import contextlib
 import ctypes as C
 from typing import NamedTuple
 
@@ -116,10 +117,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, use_sa,
-                                 debug, pose_Rt=None, pose_quat=None):
+                                 debug, pose_Rt=None, pose_quat=None, grad_sink=None):
     """_C.rasterize_gaussians_backward (rasterize_points.cu:140-239): returns
     (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dtransMat[P,9], dL_dsh[P,M,3],
-     dL_dscales[P,2], dL_drotations[P,4])."""
+     dL_dscales[P,2], dL_drotations[P,4]).
+    grad_sink (optional): dict with any of means3D / opacities / scales / rotations / colors -> contiguous fp32 tensor of
+    the gradient's shape; the kernels then write those gradients there (e.g. straight into the all-reduce bucket) instead
+    of into fresh tensors."""
     for name, t in (("background", background), ("means3D", means3D), ("radii", radii), ("colors", colors),
                     ("scales", scales), ("rotations", rotations), ("transMat_precomp", transMat_precomp),
                     ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("sh", sh), ("campos", campos),
@@ -134,6 +138,16 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     z = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dnormal = z(P, 3), z(P, 3), z(P, NUM_CHANNELS), z(P, 3)
     dL_dopacity, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations = z(P, 1), z(P, 9), z(P, M, 3), z(P, 2), z(P, 4)
+    if grad_sink:
+        def sunk(name, t):
+            s = grad_sink.get(name)
+            if s is None:
+                return t
+            if s.shape != t.shape or s.dtype != torch.float32 or s.device != dev or not s.is_contiguous():
+                raise RuntimeError(f"grad_sink[{name!r}] must be a contiguous fp32 {tuple(t.shape)} tensor on {dev}")
+            return s.detach()  # fresh tensor object on the same memory, so autograd can adopt it as .grad without a copy
+        dL_dmeans3D, dL_dcolors, dL_dopacity = sunk("means3D", dL_dmeans3D), sunk("colors", dL_dcolors), sunk("opacities", dL_dopacity)
+        dL_dscales, dL_drotations = sunk("scales", dL_dscales), sunk("rotations", dL_drotations)
     if P != 0:
         keep = [_f32c(t) for t in (background, means3D, sh, colors, scales, rotations, transMat_precomp, viewmatrix,
                                    projmatrix, campos, dL_dout_color, dL_dout_others)]
@@ -177,6 +191,24 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     return present
 
 
+class _Sink:  # process-wide on purpose: autograd runs CUDA backward nodes on its own device thread, not the caller's
+    views = None
+
+
+_SINK = _Sink()
+
+
+@contextlib.contextmanager
+def grad_sink(views):
+    """While active, the NEXT operator backward in this process writes its parameter gradients into `views`
+    (see rasterize_gaussians_backward).  Used by ba_shard to produce gradients directly in the all-reduce bucket."""
+    _SINK.views = views
+    try:
+        yield
+    finally:
+        _SINK.views = None
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     """RAST/gaus_2dgs_rasterization/__init__.py:44-161."""
 
@@ -200,11 +232,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
+        sink = getattr(_SINK, "views", None)
+        _SINK.views = None  # one backward per sink
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, sh, rs.sh_degree, rs.campos, geomBuffer,
-            ctx.num_rendered, binningBuffer, imgBuffer, rs.use_sa, rs.debug)
+            ctx.num_rendered, binningBuffer, imgBuffer, rs.use_sa, rs.debug, grad_sink=sink)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
                 grad_cov3Ds_precomp, None)
 
