@@ -10,13 +10,16 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libgs2d_hip.so")
+# GS2D_LIB_PATH: load a pre-built variant instead (kernel experiments, scripts/dev/); never set in normal use
+LIB_PATH = os.environ.get("GS2D_LIB_PATH") or os.path.join(LIB_DIR, "libgs2d_hip.so")
 SOURCES = ["gs2d_preprocess.hip", "gs2d_binning.hip", "gs2d_blend.hip", "gs2d_api.hip", "sknn.hip", "gs2d_loss.hip", "gs2d_adam.hip"]
 # -ffp-contract=off: the per-Gaussian geometry (tile rectangles, depth keys) must be reproducible on the host.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 
 
 def _stale():
+    if os.environ.get("GS2D_LIB_PATH"):
+        return False
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)

@@ -159,6 +159,23 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifdef GS2D_PROFILE_WAVES
+// dev-only instrumentation (scripts/dev/wave_profile.py): per wave [start, end, trips, hw_id] for the last launch
+__device__ unsigned long long g_wave_prof[2][4 * 8192 * 4];
+#define GS2D_PROF_BEGIN() const unsigned long long prof_t0 = wall_clock64(); unsigned int prof_trips = 0
+#define GS2D_PROF_TRIP() prof_trips++
+#define GS2D_PROF_END(K)                                                                                             \
+    if (lane == 0 && blockIdx.x < 8192) {                                                                            \
+        unsigned long long* pp = g_wave_prof[K] + ((size_t)blockIdx.x * 4 + wave) * 4;                               \
+        pp[0] = prof_t0; pp[1] = wall_clock64(); pp[2] = prof_trips;                                                 \
+        pp[3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); \
+    }
+#else
+#define GS2D_PROF_BEGIN()
+#define GS2D_PROF_TRIP()
+#define GS2D_PROF_END(K)
+#endif
+
 // ------------------------------------------------------------------------------------------- forward
 // One wave per 8x8 pixel quadrant, 4 independent waves per 16x16 tile; inside the wave each 16-lane DPP row owns
 // one 4x4 sub-block.  Per 64-splat batch: lane i fetches record i, tests it against the four sub-blocks
@@ -167,9 +184,12 @@ __device__ __forceinline__ void wave_lds_sync()
 // (per-row address, 5 x ds_read_b128, software-pipelined one trip ahead), so the four rows composite four different
 // splats at once: per-pixel order is untouched (a splat that touches several sub-blocks sits in several queues), the
 // trip count is the LONGEST queue instead of the whole list, and the VALU executes only per-pixel math.
-__device__ __forceinline__ int row_select(int row, int j0, int j1, int j2, int j3)
+__device__ __forceinline__ int row_select(int row8, int j0, int j1, int j2, int j3)
 {
-    return row == 0 ? j0 : (row == 1 ? j1 : (row == 2 ? j2 : j3));
+    // j0..j3 are wave-uniform (<= 64): pack them into one scalar and let every lane extract its row's byte with a single
+    // v_bfe_u32 (row8 = 8 * row) instead of a chain of selects
+    const uint32_t packed = (uint32_t)j0 | ((uint32_t)j1 << 8) | ((uint32_t)j2 << 16) | ((uint32_t)j3 << 24);
+    return (int)((packed >> row8) & 0xffu);
 }
 // pops the lowest set bit of a queue; 64 = empty
 __device__ __forceinline__ int pop_front(uint64_t& m)
@@ -200,6 +220,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     WaveBatch& wb = batches[wave];
     const int qx0 = tx * GS2D_TILE + (wave & 1) * 8, qy0 = ty * GS2D_TILE + (wave >> 1) * 8;
     const int row = lane >> 4, li = lane & 15;                       // DPP row = 4x4 sub-block
+    const int row8 = row * 8;
     const int lx = (row & 1) * 4 + (li & 3), ly = (row >> 1) * 4 + (li >> 2);  // position inside the quadrant
     const int px = qx0 + lx, py = qy0 + ly;
     const bool inside = px < W && py < H;
@@ -212,6 +233,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     uint32_t median_contributor = 0;  // the reference keeps a float initialised to -1 and stores (uint) -> 0
     uint32_t last_contributor = 0;
     bool done = !inside;
+    GS2D_PROF_BEGIN();
 
     for (uint32_t base = range.x; base < range.y; base += 64) {
         if (__ballot(!done) == 0) break;
@@ -235,15 +257,16 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         int j;
         {
             const int j0 = pop_front(m0), j1 = pop_front(m1), j2 = pop_front(m2), j3 = pop_front(m3);
-            j = row_select(row, j0, j1, j2, j3);
+            j = row_select(row8, j0, j1, j2, j3);
         }
         float4 a0 = wb.q[0][j & 63], a1 = wb.q[1][j & 63], a2 = wb.q[2][j & 63], a3 = wb.q[3][j & 63], a4 = wb.q[4][j & 63];
         float4 b0, b1, b2, b3, b4;
 #define GS2D_FWD_STEP(C0, C1, C2, C3, C4, N0_, N1_, N2_, N3_, N4_)                                                   \
         {                                                                                                            \
+            GS2D_PROF_TRIP();                                                                                        \
             const bool more = (m0 | m1 | m2 | m3) != 0;                                                              \
             const int nj0 = pop_front(m0), nj1 = pop_front(m1), nj2 = pop_front(m2), nj3 = pop_front(m3);            \
-            const int jn = row_select(row, nj0, nj1, nj2, nj3);                                                      \
+            const int jn = row_select(row8, nj0, nj1, nj2, nj3);                                                     \
             N0_ = wb.q[0][jn & 63]; N1_ = wb.q[1][jn & 63]; N2_ = wb.q[2][jn & 63]; N3_ = wb.q[3][jn & 63];          \
             N4_ = wb.q[4][jn & 63];                                                                                  \
             float alpha, depth;                                                                                      \
@@ -290,6 +313,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         }
 #undef GS2D_FWD_STEP
     }
+    GS2D_PROF_END(0)
     if (inside) {  // forward.cu:441-466
         const size_t HW = (size_t)H * W;
         const size_t pix = (size_t)W * py + px;
@@ -397,15 +421,47 @@ __device__ __forceinline__ int reduce16_index(int lane)
 // reduce four different splats at once (scripts/dev/reduce16_row_probe.hip).
 __device__ __forceinline__ float reduce16_row(const float v[16], int lane)
 {
-    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
-    float e[8], f[4], g[2];
-#pragma unroll
-    for (int i = 0; i < 8; i++) e[i] = seladd<0x140>(v[2 * i], v[2 * i + 1], b3);  // row_mirror: l <-> 15-l
-#pragma unroll
-    for (int i = 0; i < 4; i++) f[i] = seladd<0x141>(e[2 * i], e[2 * i + 1], b2);  // row_half_mirror: l <-> l^7
-#pragma unroll
-    for (int i = 0; i < 2; i++) g[i] = seladd<0x4E>(f[2 * i], f[2 * i + 1], b1);   // quad_perm [2,3,0,1]
-    return seladd<0xB1>(g[0], g[1], b0);                                            // quad_perm [1,0,3,2]
+    // Levels 1 and 2 pair lanes across DPP banks (l <-> 15-l flips bit 3, l <-> l^7 flips bit 2), so "lanes with the bit
+    // set keep the odd value" is a bank mask: sum the even value on all lanes, then overwrite banks {2,3} (resp. {1,3})
+    // with the sum of the odd value -- two DPP adds per output and no selects.  Same operands and order as
+    // keep + partner(give), so the sums are bit-identical.  (s_nop: VALU write -> DPP read needs 2 wait states and the
+    // compiler does not look inside asm blocks.)
+    float e0, e1, e2, e3, e4, e5, e6, e7, f0, f1, f2, f3;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %10, %10 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %12, %12 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %14, %14 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %16, %16 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %18, %18 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %20, %20 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %7, %22, %22 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %9, %9 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %11, %11 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %13, %13 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %15, %15 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %17, %17 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %5, %19, %19 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %6, %21, %21 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %7, %23, %23 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1"
+        : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(e4), "=&v"(e5), "=&v"(e6), "=&v"(e7)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]),
+          "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+    asm("v_add_f32_dpp %0, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %10, %10 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %11, %11 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1"
+        : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3)
+        : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(e4), "v"(e5), "v"(e6), "v"(e7));
+    const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+    const float g0 = seladd<0x4E>(f0, f1, b1), g1 = seladd<0x4E>(f2, f3, b1);  // quad_perm [2,3,0,1]
+    return seladd<0xB1>(g0, g1, b0);                                            // quad_perm [1,0,3,2]
 }
 __device__ __forceinline__ int reduce16_row_index(int lane)
 {
@@ -442,6 +498,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     WaveBatch& wb = batches[wave];
     const int qx0 = tx * GS2D_TILE + (wave & 1) * 8, qy0 = ty * GS2D_TILE + (wave >> 1) * 8;
     const int row = lane >> 4, li = lane & 15;                       // DPP row = 4x4 sub-block (same mapping as the forward)
+    const int row8 = row * 8;
     const int px = qx0 + (row & 1) * 4 + (li & 3), py = qy0 + (row >> 1) * 4 + (li >> 2);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
@@ -494,6 +551,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     // dL_dnormal / the normal term of dL_dalpha is exactly zero and is skipped.  Results are unchanged.
     const bool any_dn = __ballot(dn0 != 0.f || dn1 != 0.f || dn2 != 0.f) != 0;
     const int nbatches = (int)((max_last + 63) / 64);
+    GS2D_PROF_BEGIN();
     for (int b = nbatches - 1; b >= 0; b--) {
         const uint32_t b0 = (uint32_t)b * 64;
         const int n = (int)min(64u, max_last - b0);
@@ -516,14 +574,15 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         int j;
         {
             const int j0 = pop_back(m0), j1 = pop_back(m1), j2 = pop_back(m2), j3 = pop_back(m3);
-            j = row_select(row, j0, j1, j2, j3);
+            j = row_select(row8, j0, j1, j2, j3);
         }
         float4 ga0 = wb.q[0][j & 63], ga1 = wb.q[1][j & 63], ga2 = wb.q[2][j & 63];
         float4 gb0, gb1, gb2;
 #define GS2D_BWD_STEP(G0, G1, G2, N0_, N1_, N2_)                                                                      \
         {                                                                                                             \
+            GS2D_PROF_TRIP();                                                                                         \
             const bool more = (m0 | m1 | m2 | m3) != 0;                                                               \
-            const int jn = row_select(row, pop_back(m0), pop_back(m1), pop_back(m2), pop_back(m3));                   \
+            const int jn = row_select(row8, pop_back(m0), pop_back(m1), pop_back(m2), pop_back(m3));                  \
             N0_ = wb.q[0][jn & 63]; N1_ = wb.q[1][jn & 63]; N2_ = wb.q[2][jn & 63];                                   \
             const float4 c3 = wb.q[3][j & 63], c4 = wb.q[4][j & 63];                                                  \
             const uint32_t contributor = b0 + (uint32_t)j; /* 0-based, as in backward.cu:285 */                       \
@@ -648,6 +707,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         }
 #undef GS2D_BWD_STEP
     }
+    GS2D_PROF_END(1)
 }
 
 }  // namespace
@@ -683,3 +743,12 @@ void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_l
 }
 
 }  // namespace gs2d
+
+#ifdef GS2D_PROFILE_WAVES
+extern "C" int gs2d_debug_read_wave_profile(int kernel, unsigned long long* host_out, size_t n_words)
+{
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wave_prof), n_words * 8, (size_t)kernel * 4 * 8192 * 4 * 8,
+                               hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
