@@ -159,6 +159,19 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// dev-only experiment hooks (scripts/dev/variants.sh); empty in the product build
+#if defined(GS2D_EXPERIMENT) && GS2D_EXPERIMENT == 1
+#define GS2D_EXP_ATOMIC(X) if (tot == 123.456f) dst[ridx] = tot;
+#elif defined(GS2D_EXPERIMENT) && GS2D_EXPERIMENT == 3
+#define GS2D_EXP_ATOMIC(X) if (tot != 0.f) __hip_atomic_fetch_add(dst + ridx, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+#define GS2D_EXP_ATOMIC(X) X
+#endif
+#if defined(GS2D_EXPERIMENT) && GS2D_EXPERIMENT == 2
+#define GS2D_EXP_BUTTERFLY tot = (g[0] + g[3]) + (g[9] + g[15]) + g[1] + g[2] + g[4] + g[5] + g[6] + g[7] + g[8] + g[10] + g[11]; if (false)
+#else
+#define GS2D_EXP_BUTTERFLY
+#endif
 #ifdef GS2D_PROFILE_WAVES
 // dev-only instrumentation (scripts/dev/wave_profile.py): per wave [start, end, trips, hw_id] for the last launch
 __device__ unsigned long long g_wave_prof[2][4 * 8192 * 4];
@@ -207,14 +220,29 @@ __device__ __forceinline__ int pop_back(uint64_t& m)
     return j;
 }
 
+// XCD-aware workgroup -> tile mapping.  Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own
+// L2.  Handing XCD x the x-th contiguous band of tiles (row-major) keeps the tiles a Gaussian touches on ONE XCD in all
+// but the band-border cases, so its gradient record is accumulated by atomics in a single L2 instead of bouncing
+// between the L2s of neighbouring tiles' XCDs (measured: ~30% of the backward), and record gathers hit in L2.
+// Purely a placement heuristic: any dispatch order gives the same results.
+#define GS2D_XCDS 8
+__device__ __forceinline__ int xcd_tile(int block, int ntiles)
+{
+    const int chunk = (ntiles + GS2D_XCDS - 1) / GS2D_XCDS;
+    const int k = block / GS2D_XCDS;
+    const int tile = (block % GS2D_XCDS) * chunk + k;
+    return tile < ntiles ? tile : -1;  // the last band may be short
+}
+
 template <bool USE_SA>
 __global__ void __launch_bounds__(256)
-blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
                  float* __restrict__ out_others, float* __restrict__ pix_state, size_t plane, uint8_t* __restrict__ hits)
 {
     __shared__ WaveBatch batches[4];
-    const int tile = blockIdx.x;
+    const int tile = xcd_tile(blockIdx.x, ntiles);
+    if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     WaveBatch& wb = batches[wave];
@@ -463,6 +491,44 @@ __device__ __forceinline__ float reduce16_row(const float v[16], int lane)
     const float g0 = seladd<0x4E>(f0, f1, b1), g1 = seladd<0x4E>(f2, f3, b1);  // quad_perm [2,3,0,1]
     return seladd<0xB1>(g0, g1, b0);                                            // quad_perm [1,0,3,2]
 }
+// reduce16_row for inputs whose values 12, 13 and 14 are exact zeros on every lane (no upstream gradient on the normal
+// channels): the (12,13) pair and half of the (14,15) subtree vanish.  Lanes that would hold 12..14 end with +0.
+__device__ __forceinline__ float reduce16_row_z(const float v[16], int lane)
+{
+    float e0, e1, e2, e3, e4, e5, e7, f0, f1, f2, f3;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %7, %7 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %11, %11 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %13, %13 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %15, %15 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %17, %17 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %19, %19 row_mirror row_mask:0xf bank_mask:0xf\n\t"   /* value 15; only banks 2,3 are used */
+        "v_add_f32_dpp %0, %8, %8 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %10, %10 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %12, %12 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %14, %14 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %16, %16 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %5, %18, %18 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1"
+        : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(e4), "=&v"(e5), "=&v"(e7)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]),
+          "v"(v[10]), "v"(v[11]), "v"(v[15]));
+    f3 = 0.f;
+    asm("v_add_f32_dpp %0, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %10, %10 row_half_mirror row_mask:0xf bank_mask:0x8\n\t"  /* lanes 12-15 <- value 15 */
+        "v_add_f32_dpp %0, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1"
+        : "=&v"(f0), "=&v"(f1), "=&v"(f2), "+v"(f3)
+        : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(e4), "v"(e5), "v"(e7));
+    const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+    const float g0 = seladd<0x4E>(f0, f1, b1), g1 = seladd<0x4E>(f2, f3, b1);
+    return seladd<0xB1>(g0, g1, b0);
+}
 __device__ __forceinline__ int reduce16_row_index(int lane)
 {
     return 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
@@ -484,18 +550,32 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
 // main components are reduced with the butterfly above and added with ONE global atomic instruction whose 16
 // active lanes cover 64 contiguous bytes of the Gaussian's record (the reference issues 16-18 atomics per
 // (pixel, splat) pair).
+// Wave-private LDS of the backward: a 64-byte staged record per splat of the batch (Tu|cx, Tv|cy, Tw|opacity,
+// r,g,b,id -- the normal is fetched from global memory only by waves that carry normal gradients) and 13 gradient
+// accumulators per splat (3 colour, 9 dT, 1 opacity).  The gradient atomics are the backward's scarcest resource
+// (scripts/dev/atomic_bench.hip: the kernel's former atomic stream alone takes ~360 us on the whole chip), so every
+// (row, splat) contribution is first added into LDS (ds_add_f32) and each touched splat of the batch is flushed to its
+// global record ONCE per (quadrant, batch) -- about half as many global atomics, three quarters of a workgroup's LDS
+// budget (29.6 KB, 5 workgroups per CU).
+#define GS2D_ACC 13
+struct BwdBatch {
+    float4 q[4][64];
+    float acc[64 * GS2D_ACC];
+};
+
 template <bool USE_SA>
-__global__ void __launch_bounds__(256)
-blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
+blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ pix_state,
                  size_t plane, const uint8_t* __restrict__ hits, const float* __restrict__ dL_dpix,
                  const float* __restrict__ dL_dothers, float* __restrict__ grad_rec)
 {
-    __shared__ WaveBatch batches[4];
-    const int tile = blockIdx.x;
+    __shared__ BwdBatch batches[4];
+    const int tile = xcd_tile(blockIdx.x, ntiles);
+    if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    WaveBatch& wb = batches[wave];
+    BwdBatch& wb = batches[wave];
     const int qx0 = tx * GS2D_TILE + (wave & 1) * 8, qy0 = ty * GS2D_TILE + (wave >> 1) * 8;
     const int row = lane >> 4, li = lane & 15;                       // DPP row = 4x4 sub-block (same mapping as the forward)
     const int row8 = row * 8;
@@ -545,7 +625,13 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     for (int d = 32; d >= 1; d >>= 1) max_last = max(max_last, (uint32_t)__shfl_xor((int)max_last, d, 64));
     max_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_last);
 
-    const int ridx = reduce16_row_index(lane);
+    // butterfly slot held by this lane -> offset in the gradient record, and the sign of that component.  Slots:
+    // 0-2 colour | 3-8 Tu,Tv (accumulated as +dk,+dl, the record wants -dk,-dl) | 9-11 Tw | 12-14 normal | 15 opacity
+    const int slot = reduce16_row_index(lane);
+    const uint32_t slot_sign = (slot >= 3 && slot <= 8) ? 0x80000000u : 0u;
+    const int acc_comp = slot < 12 ? slot : (slot == 15 ? 12 : -1);  // LDS accumulator of this lane's slot; -1: normal (global)
+#pragma unroll
+    for (int i = 0; i < GS2D_ACC; i++) wb.acc[i * 64 + lane] = 0.f;
     // Wave-uniform data-dependent shortcut: when no pixel of this quadrant carries an upstream gradient on the
     // normal channels (SLAM's losses never touch them unless use_normal_loss), everything that only feeds
     // dL_dnormal / the normal term of dL_dalpha is exactly zero and is skipped.  Results are unchanged.
@@ -560,17 +646,19 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         if (lane < n) {
             const uint32_t my_id = point_list[range.x + b0 + lane];
             const float4* rp = rec + (size_t)my_id * GS2D_REC_F4;
-            const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
-            float4 r4 = rp[4];
+            const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+            const float red = rp[3].w;
+            const float4 r4 = rp[4];
             // queues come from the cull bits the forward stored for this (instance, quadrant): no second cull test
             tm = hits[(size_t)(range.x + b0 + lane) * 4 + wave];
-            r4.w = __uint_as_float(my_id);  // the Gaussian id rides in the unused slot of the staged record
-            wb.q[0][lane] = r0; wb.q[1][lane] = r1; wb.q[2][lane] = r2; wb.q[3][lane] = r3; wb.q[4][lane] = r4;
+            wb.q[0][lane] = r0; wb.q[1][lane] = r1; wb.q[2][lane] = r2;
+            wb.q[3][lane] = make_float4(red, r4.x, r4.y, __uint_as_float(my_id));  // colour + the Gaussian id
         }
         wave_lds_sync();
         // four depth-ordered queues, one per 4x4 sub-block (= DPP row), walked back to front
         uint64_t m0 = __ballot(tm & 1u), m1 = __ballot(tm & 2u), m2 = __ballot(tm & 4u), m3 = __ballot(tm & 8u);
         if ((m0 | m1 | m2 | m3) == 0) continue;
+        uint64_t touched = m0 | m1 | m2 | m3;  // splats of this batch that may receive a gradient from this quadrant
         int j;
         {
             const int j0 = pop_back(m0), j1 = pop_back(m1), j2 = pop_back(m2), j3 = pop_back(m3);
@@ -584,7 +672,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             const bool more = (m0 | m1 | m2 | m3) != 0;                                                               \
             const int jn = row_select(row8, pop_back(m0), pop_back(m1), pop_back(m2), pop_back(m3));                  \
             N0_ = wb.q[0][jn & 63]; N1_ = wb.q[1][jn & 63]; N2_ = wb.q[2][jn & 63];                                   \
-            const float4 c3 = wb.q[3][j & 63], c4 = wb.q[4][j & 63];                                                  \
+            const float4 cc = wb.q[3][j & 63]; /* r, g, b, id */                                                      \
             const uint32_t contributor = b0 + (uint32_t)j; /* 0-based, as in backward.cu:285 */                       \
             bool active = inside && j < 64 && contributor < last_contributor; /* j == 64: row queue exhausted */      \
             if (__ballot(active) != 0) {                                                                              \
@@ -614,12 +702,12 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                     const float w = alpha * T;                                                                        \
                     float dL_dalpha = 0.0f;                                                                           \
                     /* backward.cu:331-344 */                                                                         \
-                    ar0 = fmaf(last_alpha, lc0, (1.f - last_alpha) * ar0); lc0 = c3.w;                                \
-                    dL_dalpha = fmaf(c3.w - ar0, dpx0, dL_dalpha);                                                    \
-                    ar1 = fmaf(last_alpha, lc1, (1.f - last_alpha) * ar1); lc1 = c4.x;                                \
-                    dL_dalpha = fmaf(c4.x - ar1, dpx1, dL_dalpha);                                                    \
-                    ar2 = fmaf(last_alpha, lc2, (1.f - last_alpha) * ar2); lc2 = c4.y;                                \
-                    dL_dalpha = fmaf(c4.y - ar2, dpx2, dL_dalpha);                                                    \
+                    ar0 = fmaf(last_alpha, lc0, (1.f - last_alpha) * ar0); lc0 = cc.x;                                \
+                    dL_dalpha = fmaf(cc.x - ar0, dpx0, dL_dalpha);                                                    \
+                    ar1 = fmaf(last_alpha, lc1, (1.f - last_alpha) * ar1); lc1 = cc.y;                                \
+                    dL_dalpha = fmaf(cc.y - ar1, dpx1, dL_dalpha);                                                    \
+                    ar2 = fmaf(last_alpha, lc2, (1.f - last_alpha) * ar2); lc2 = cc.z;                                \
+                    dL_dalpha = fmaf(cc.z - ar2, dpx2, dL_dalpha);                                                    \
                     float conf = 1.f;                                                                                 \
                     if (USE_SA) { /* backward.cu:347-351 */                                                           \
                         if (T < 0.5f) {                                                                               \
@@ -651,13 +739,14 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                     dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);                                    \
                     accum_alpha_rec = fmaf(1.f - last_alpha, accum_alpha_rec, last_alpha);                            \
                     dL_dalpha = fmaf(1 - accum_alpha_rec, dL_daccum, dL_dalpha);                                      \
-                    if (any_dn) { /* backward.cu:392-397 */                                                           \
-                        an0 = fmaf(last_alpha, ln0, (1.f - last_alpha) * an0); ln0 = c3.x;                            \
-                        dL_dalpha = fmaf(c3.x - an0, dn0, dL_dalpha);                                                 \
-                        an1 = fmaf(last_alpha, ln1, (1.f - last_alpha) * an1); ln1 = c3.y;                            \
-                        dL_dalpha = fmaf(c3.y - an1, dn1, dL_dalpha);                                                 \
-                        an2 = fmaf(last_alpha, ln2, (1.f - last_alpha) * an2); ln2 = c3.z;                            \
-                        dL_dalpha = fmaf(c3.z - an2, dn2, dL_dalpha);                                                 \
+                    if (any_dn) { /* backward.cu:392-397; the normal is not staged: rare path, read it from the record */ \
+                        const float4 nn = rec[(size_t)__float_as_uint(cc.w) * GS2D_REC_F4 + 3];                       \
+                        an0 = fmaf(last_alpha, ln0, (1.f - last_alpha) * an0); ln0 = nn.x;                            \
+                        dL_dalpha = fmaf(nn.x - an0, dn0, dL_dalpha);                                                 \
+                        an1 = fmaf(last_alpha, ln1, (1.f - last_alpha) * an1); ln1 = nn.y;                            \
+                        dL_dalpha = fmaf(nn.y - an1, dn1, dL_dalpha);                                                 \
+                        an2 = fmaf(last_alpha, ln2, (1.f - last_alpha) * an2); ln2 = nn.z;                            \
+                        dL_dalpha = fmaf(nn.z - an2, dn2, dL_dalpha);                                                 \
                     }                                                                                                 \
                     dL_dalpha *= T;                                                                                   \
                     last_alpha = alpha;                                                                               \
@@ -674,27 +763,40 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                 if (__ballot(active) != 0) {                                                                          \
                     float g[16];                                                                                      \
                     g[0] = d_w * dpx0; g[1] = d_w * dpx1; g[2] = d_w * dpx2;                                          \
-                    g[3] = d_w * dn0; g[4] = d_w * dn1; g[5] = d_w * dn2;                                             \
                     const float dL_ds0 = fmaf(d_gG, s0, d_zr * G2.x);                                                 \
                     const float dL_ds1 = fmaf(d_gG, s1, d_zr * G2.y);                                                 \
                     const float dsx = dL_ds0 * ip, dsy = dL_ds1 * ip;                                                 \
                     const float dp2 = -fmaf(dsx, s0, dsy * s1);                                                       \
                     const float dk0 = fmaf(l1, dp2, -(l2 * dsy)), dk1 = fmaf(l2, dsx, -(l0 * dp2)), dk2 = fmaf(l0, dsy, -(l1 * dsx)); \
                     const float dl0 = fmaf(dsy, k2, -(dp2 * k1)), dl1 = fmaf(dp2, k0, -(dsx * k2)), dl2 = fmaf(dsx, k1, -(dsy * k0)); \
-                    g[6] = -dk0; g[7] = -dk1; g[8] = -dk2;                                                            \
-                    g[9] = -dl0; g[10] = -dl1; g[11] = -dl2;                                                          \
-                    g[12] = fmaf(pxf, dk0, fmaf(pyf, dl0, d_zr * s0));                                                \
-                    g[13] = fmaf(pxf, dk1, fmaf(pyf, dl1, d_zr * s1));                                                \
-                    g[14] = fmaf(pxf, dk2, fmaf(pyf, dl2, d_zr)) + d_zl;                                              \
+                    g[3] = dk0; g[4] = dk1; g[5] = dk2; /* the record holds -dk, -dl: negated after the reduction (exact) */ \
+                    g[6] = dl0; g[7] = dl1; g[8] = dl2;                                                               \
+                    g[9] = fmaf(pxf, dk0, fmaf(pyf, dl0, d_zr * s0));                                                 \
+                    g[10] = fmaf(pxf, dk1, fmaf(pyf, dl1, d_zr * s1));                                                \
+                    g[11] = fmaf(pxf, dk2, fmaf(pyf, dl2, d_zr)) + d_zl;                                              \
                     g[15] = d_op;                                                                                     \
-                    /* each row reduces ITS splat; one atomic instruction then adds 4 x 64 contiguous bytes */        \
-                    float* dst = grad_rec + (size_t)__float_as_uint(c4.w) * GS2D_GRAD_FLOATS;                         \
-                    const float tot = reduce16_row(g, lane);                                                          \
-                    if (tot != 0.f) atomicAdd(dst + ridx, tot); /* rows without a contributing lane sum to +0 */      \
+                    /* each row reduces ITS splat into the splat's LDS accumulators */                                \
+                    float tot;                                                                                        \
+                    GS2D_EXP_BUTTERFLY                                                                                \
+                    if (any_dn) {                                                                                     \
+                        g[12] = d_w * dn0; g[13] = d_w * dn1; g[14] = d_w * dn2;                                      \
+                        tot = reduce16_row(g, lane);                                                                  \
+                    } else {                                                                                          \
+                        g[12] = 0.f; g[13] = 0.f; g[14] = 0.f;                                                        \
+                        tot = reduce16_row_z(g, lane);                                                                \
+                    }                                                                                                 \
+                    tot = __uint_as_float(__float_as_uint(tot) ^ slot_sign);                                          \
+                    /* rows without a contributing lane (or an exhausted queue, j == 64 -> slot 0) add +-0 */         \
+                    if (acc_comp >= 0) atomicAdd(&wb.acc[(j & 63) * GS2D_ACC + acc_comp], tot);                       \
+                    else if (any_dn && tot != 0.f)                                                                    \
+                        atomicAdd(grad_rec + (size_t)__float_as_uint(cc.w) * GS2D_GRAD_FLOATS + (slot - 9), tot);                                   \
                     if (__ballot(d_t != 0.f) != 0) {                                                                  \
                         const float g_mx = row_sum_to_lane15(d_t * d0);                                               \
                         const float g_my = row_sum_to_lane15(d_t * d1);                                               \
-                        if (li == 15 && (g_mx != 0.f || g_my != 0.f)) { atomicAdd(dst + 16, g_mx); atomicAdd(dst + 17, g_my); } \
+                        if (li == 15 && (g_mx != 0.f || g_my != 0.f)) {                                               \
+                            float* dst = grad_rec + (size_t)__float_as_uint(cc.w) * GS2D_GRAD_FLOATS;                 \
+                            atomicAdd(dst + 16, g_mx); atomicAdd(dst + 17, g_my);                                     \
+                        } \
                     }                                                                                                 \
                 }                                                                                                     \
             }                                                                                                         \
@@ -706,6 +808,21 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             GS2D_BWD_STEP(gb0, gb1, gb2, ga0, ga1, ga2)
         }
 #undef GS2D_BWD_STEP
+        // flush: every touched splat of the batch goes to its global record once, four splats (one per row) per pass
+        while (touched) {
+            const int f0 = pop_front(touched), f1 = pop_front(touched), f2 = pop_front(touched), f3 = pop_front(touched);
+            const int jf = row_select(row8, f0, f1, f2, f3);
+            if (jf < 64 && li < GS2D_ACC) {
+                float* a = &wb.acc[jf * GS2D_ACC + li];
+                const float v = *a;
+                if (v != 0.f) {
+                    *a = 0.f;
+                    // lane li < 13 owns accumulator li of its row's splat: record offsets 0-2 colour, 6-14 dT, 15 opacity
+                    const int flush_off = li < 3 ? li : (li < 12 ? li + 3 : 15);
+                    atomicAdd(grad_rec + (size_t)__float_as_uint(wb.q[3][jf].w) * GS2D_GRAD_FLOATS + flush_off, v);
+                }
+            }
+        }
     }
     GS2D_PROF_END(1)
 }
@@ -720,11 +837,12 @@ void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_l
 {
     const int gx = (W + GS2D_TILE - 1) / GS2D_TILE, gy = (H + GS2D_TILE - 1) / GS2D_TILE;
     const size_t plane = (size_t)gx * gy * GS2D_TILE_PIX;
+    const int grid = GS2D_XCDS * ((gx * gy + GS2D_XCDS - 1) / GS2D_XCDS);
     if (use_sa)
-        hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(gx * gy), dim3(256), 0, s, W, H, gx, ranges, point_list, rec,
+        hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, W, H, gx, gx * gy, ranges, point_list, rec,
                            bg, out_color, out_others, pix_state, plane, hits);
     else
-        hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(gx * gy), dim3(256), 0, s, W, H, gx, ranges, point_list, rec,
+        hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, W, H, gx, gx * gy, ranges, point_list, rec,
                            bg, out_color, out_others, pix_state, plane, hits);
 }
 
@@ -734,11 +852,12 @@ void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_l
 {
     const int gx = (W + GS2D_TILE - 1) / GS2D_TILE, gy = (H + GS2D_TILE - 1) / GS2D_TILE;
     const size_t plane = (size_t)gx * gy * GS2D_TILE_PIX;
+    const int grid = GS2D_XCDS * ((gx * gy + GS2D_XCDS - 1) / GS2D_XCDS);
     if (use_sa)
-        hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(gx * gy), dim3(256), 0, s, W, H, gx, ranges, point_list, rec,
+        hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(grid), dim3(256), 0, s, W, H, gx, gx * gy, ranges, point_list, rec,
                            bg, pix_state, plane, hits, dL_dpix, dL_dothers, grad_rec);
     else
-        hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(gx * gy), dim3(256), 0, s, W, H, gx, ranges, point_list, rec,
+        hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(grid), dim3(256), 0, s, W, H, gx, gx * gy, ranges, point_list, rec,
                            bg, pix_state, plane, hits, dL_dpix, dL_dothers, grad_rec);
 }
 
