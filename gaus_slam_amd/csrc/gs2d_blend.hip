@@ -161,11 +161,19 @@ __device__ __forceinline__ void wave_lds_sync()
 
 // dev-only experiment hooks (scripts/dev/variants.sh); empty in the product build
 #if defined(GS2D_EXPERIMENT) && GS2D_EXPERIMENT == 1
-#define GS2D_EXP_ATOMIC(X) if (tot == 123.456f) dst[ridx] = tot;
-#elif defined(GS2D_EXPERIMENT) && GS2D_EXPERIMENT == 3
-#define GS2D_EXP_ATOMIC(X) if (tot != 0.f) __hip_atomic_fetch_add(dst + ridx, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#define GS2D_EXP_ATOMIC(X) if (va == 123.456f) grad_rec[flush_off] = vb;
 #else
 #define GS2D_EXP_ATOMIC(X) X
+#endif
+#if defined(GS2D_EXPERIMENT) && GS2D_EXPERIMENT == 4
+#define GS2D_EXP_FLUSH(T) ((T) == 12345ull)
+#else
+#define GS2D_EXP_FLUSH(T) (T)
+#endif
+#if defined(GS2D_EXPERIMENT) && GS2D_EXPERIMENT == 5
+#define GS2D_EXP_LDSADD(P, V) *(P) = (V)
+#else
+#define GS2D_EXP_LDSADD(P, V) atomicAdd(P, V)
 #endif
 #if defined(GS2D_EXPERIMENT) && GS2D_EXPERIMENT == 2
 #define GS2D_EXP_BUTTERFLY tot = (g[0] + g[3]) + (g[9] + g[15]) + g[1] + g[2] + g[4] + g[5] + g[6] + g[7] + g[8] + g[10] + g[11]; if (false)
@@ -786,8 +794,8 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                         tot = reduce16_row_z(g, lane);                                                                \
                     }                                                                                                 \
                     tot = __uint_as_float(__float_as_uint(tot) ^ slot_sign);                                          \
-                    /* rows without a contributing lane (or an exhausted queue, j == 64 -> slot 0) add +-0 */         \
-                    if (acc_comp >= 0) atomicAdd(&wb.acc[(j & 63) * GS2D_ACC + acc_comp], tot);                       \
+                    /* LDS float atomics run at a few lanes per clock: rows/components that sum to +-0 skip them */    \
+                    if (acc_comp >= 0 && tot != 0.f) GS2D_EXP_LDSADD(&wb.acc[(j & 63) * GS2D_ACC + acc_comp], tot);   \
                     else if (any_dn && tot != 0.f)                                                                    \
                         atomicAdd(grad_rec + (size_t)__float_as_uint(cc.w) * GS2D_GRAD_FLOATS + (slot - 9), tot);                                   \
                     if (__ballot(d_t != 0.f) != 0) {                                                                  \
@@ -809,18 +817,23 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
         }
 #undef GS2D_BWD_STEP
         // flush: every touched splat of the batch goes to its global record once, four splats (one per row) per pass
-        while (touched) {
-            const int f0 = pop_front(touched), f1 = pop_front(touched), f2 = pop_front(touched), f3 = pop_front(touched);
-            const int jf = row_select(row8, f0, f1, f2, f3);
-            if (jf < 64 && li < GS2D_ACC) {
-                float* a = &wb.acc[jf * GS2D_ACC + li];
-                const float v = *a;
-                if (v != 0.f) {
-                    *a = 0.f;
-                    // lane li < 13 owns accumulator li of its row's splat: record offsets 0-2 colour, 6-14 dT, 15 opacity
-                    const int flush_off = li < 3 ? li : (li < 12 ? li + 3 : 15);
-                    atomicAdd(grad_rec + (size_t)__float_as_uint(wb.q[3][jf].w) * GS2D_GRAD_FLOATS + flush_off, v);
-                }
+        // two passes (eight splats) per iteration so the LDS round trips of one pass hide behind the other
+        const int flush_off = li < 3 ? li : (li < 12 ? li + 3 : 15);  // accumulator li -> offset in the gradient record
+        const bool flush_lane = li < GS2D_ACC;
+        while (GS2D_EXP_FLUSH(touched)) {
+            const int fa = row_select(row8, pop_front(touched), pop_front(touched), pop_front(touched), pop_front(touched));
+            const int fb = row_select(row8, pop_front(touched), pop_front(touched), pop_front(touched), pop_front(touched));
+            float* pa = &wb.acc[(fa & 63) * GS2D_ACC + (flush_lane ? li : 0)];
+            float* pb = &wb.acc[(fb & 63) * GS2D_ACC + (flush_lane ? li : 0)];
+            const float va = *pa, vb = *pb;
+            const uint32_t ida = __float_as_uint(wb.q[3][fa & 63].w), idb = __float_as_uint(wb.q[3][fb & 63].w);
+            if (fa < 64 && flush_lane && va != 0.f) {
+                *pa = 0.f;
+                GS2D_EXP_ATOMIC(atomicAdd(grad_rec + (size_t)ida * GS2D_GRAD_FLOATS + flush_off, va);)
+            }
+            if (fb < 64 && flush_lane && vb != 0.f) {
+                *pb = 0.f;
+                GS2D_EXP_ATOMIC(atomicAdd(grad_rec + (size_t)idb * GS2D_GRAD_FLOATS + flush_off, vb);)
             }
         }
     }

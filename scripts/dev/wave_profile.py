@@ -1,5 +1,5 @@
 """Dev tool: per-wave start/end/trips of the two blend kernels (variant library built with -DGS2D_PROFILE_WAVES).
-Run on the GPU box:  GS2D_LIB_PATH=scripts/dev/variants/libgs2d_prof.so python scripts/dev/wave_profile.py"""
+Run on the GPU box:  GS2D_LIB_PATH=scripts/dev/variants/libprof.so python scripts/dev/wave_profile.py"""
 import ctypes as C, os, sys
 import numpy as np
 import torch
