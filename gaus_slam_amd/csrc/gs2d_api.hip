@@ -183,19 +183,19 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
 
     const int nblk = (P + GS2D_SCAN_ITEMS - 1) / GS2D_SCAN_ITEMS;
     uint32_t* total_dev = scan_tmp + nblk + 8;
-    g_timer.begin(ST_SCAN, s);
-    gs2d::launch_inclusive_scan(tiles_touched, point_offsets, P, scan_tmp, total_dev, s);
-    g_timer.end(ST_SCAN, s);
-    GS2D_STAGE("scan");
-
     // The one host sync of the forward (rasterizer_impl.cu:287): the binning chunk is sized by num_rendered.
+    // Read-back without an OS-level wait and without a copy: the scan stores the total straight into a pinned host word
+    // (system-scope store, issued as soon as the total is known) that was pre-set to a sentinel and is polled below.
+    // On a loaded host a blocking hipStreamSynchronize can cost milliseconds of scheduler latency per call; the poll
+    // returns within a microsecond of the store landing.  Falls back to a real synchronise after ~2 s (surfacing any
+    // GPU error).
     if (!g_pinned.p) GS2D_CHECK(hipHostMalloc((void**)&g_pinned.p, 64, hipHostMallocDefault), "hipHostMalloc");
-    // Read-back without an OS-level wait: the pinned word is pre-set to a sentinel and polled.  On a loaded host a
-    // blocking hipStreamSynchronize can cost milliseconds of scheduler latency per call; the poll returns within a
-    // microsecond of the copy landing.  Falls back to a real synchronise after ~2 s (surfacing any GPU error).
     volatile uint32_t* pinned = g_pinned.p;
     *pinned = 0xFFFFFFFFu;
-    GS2D_CHECK(hipMemcpyAsync(g_pinned.p, total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "memcpy num_rendered");
+    g_timer.begin(ST_SCAN, s);
+    gs2d::launch_inclusive_scan(tiles_touched, point_offsets, P, scan_tmp, total_dev, s, g_pinned.p);
+    g_timer.end(ST_SCAN, s);
+    GS2D_STAGE("scan");
     {
         const auto t0 = std::chrono::steady_clock::now();
         uint64_t spins = 0;

@@ -56,7 +56,8 @@ __global__ void __launch_bounds__(SCAN_T) scan_reduce_kernel(const uint32_t* __r
 }
 
 // exclusive scan of block sums in place (single workgroup, loops over chunks); writes grand total.
-__global__ void __launch_bounds__(SCAN_T) scan_blocksums_kernel(uint32_t* __restrict__ block_sums, int nblocks, uint32_t* __restrict__ total_out)
+__global__ void __launch_bounds__(SCAN_T) scan_blocksums_kernel(uint32_t* __restrict__ block_sums, int nblocks, uint32_t* __restrict__ total_out,
+                                                                uint32_t* __restrict__ total_host)
 {
     __shared__ uint32_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -73,6 +74,8 @@ __global__ void __launch_bounds__(SCAN_T) scan_blocksums_kernel(uint32_t* __rest
         __syncthreads();
     }
     if (threadIdx.x == 0 && total_out) *total_out = carry_s;
+    // pinned host word polled by the caller: the total is known here, one kernel before the scan itself completes
+    if (threadIdx.x == 0 && total_host) __hip_atomic_store(total_host, carry_s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void __launch_bounds__(SCAN_T) scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n,
@@ -401,12 +404,13 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t*
 
 namespace gs2d {
 
-void launch_inclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* tmp, uint32_t* total_out, hipStream_t s)
+void launch_inclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* tmp, uint32_t* total_out, hipStream_t s,
+                           uint32_t* total_host)
 {
     if (n <= 0) return;
     const int nblocks = (n + GS2D_SCAN_ITEMS - 1) / GS2D_SCAN_ITEMS;
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, in, n, tmp);
-    hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_T), 0, s, tmp, nblocks, total_out);
+    hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_T), 0, s, tmp, nblocks, total_out, total_host);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, in, out, n, tmp);
 }
 

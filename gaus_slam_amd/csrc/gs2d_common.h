@@ -123,7 +123,9 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
                            float* dL_dpose, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
 // inclusive scan of n u32; tmp must hold ceil(n/1024)+64 u32. If total_out != nullptr the grand total is stored there.
-void launch_inclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* tmp, uint32_t* total_out, hipStream_t s);
+// total_host (optional): pinned host word that receives the total with a system-scope store as soon as it is known.
+void launch_inclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* tmp, uint32_t* total_out, hipStream_t s,
+                           uint32_t* total_host = nullptr);
 void launch_duplicate(int P, const float4* rec, const float* depths, const uint32_t* offsets, const int* radii,
                       int gx, int gy, uint64_t* keys, uint32_t* vals, hipStream_t s);
 // stable LSD radix sort of (u64 key, u32 val) pairs on key bits [begin_bit, end_bit). Result lands in keys_a/vals_a;
