@@ -84,6 +84,7 @@ struct PinnedWord {
     ~PinnedWord() { if (p) (void)hipHostFree(p); }
 };
 thread_local PinnedWord g_pinned;
+thread_local uint32_t g_last_R = 0;  // previous forward's num_rendered: sizes the early binning allocation
 
 }  // namespace
 
@@ -196,6 +197,13 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     gs2d::launch_inclusive_scan(tiles_touched, point_offsets, P, scan_tmp, total_dev, s, g_pinned.p);
     g_timer.end(ST_SCAN, s);
     GS2D_STAGE("scan");
+
+    // While the GPU works towards num_rendered, ask for the binning chunk already, sized from the previous call's count
+    // (+12.5 %): the allocator callback (a trip through the caller's runtime) then costs nothing on the critical
+    // path.  If the guess turns out too small the callback is simply invoked a second time with the exact size.
+    const size_t guess_R = (size_t)g_last_R + g_last_R / 8 + 4096;
+    const size_t pre_bytes = bin_layout((int)(guess_R > 0x7fffffffull ? 0x7fffffffull : guess_R)).total;
+    char* bin_pre = (char*)binning_alloc(binning_user, pre_bytes);
     {
         const auto t0 = std::chrono::steady_clock::now();
         uint64_t spins = 0;
@@ -213,8 +221,9 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     if (num_rendered_u > 0x7fffffffu) return fail_msg("num_rendered overflows int32");
     const int R = (int)num_rendered_u;
 
-    const BinLayout BL = bin_layout(R);
-    char* bin = (char*)binning_alloc(binning_user, BL.total);
+    g_last_R = num_rendered_u;
+    const BinLayout BL = bin_layout(R);  // offsets always follow the true count; the chunk may be larger than BL.total
+    char* bin = (bin_pre && BL.total <= pre_bytes) ? bin_pre : (char*)binning_alloc(binning_user, BL.total);
     if (!bin) return fail_msg("binning allocation failed");
     uint32_t* point_list = (uint32_t*)(bin + BL.point_list);
     uint8_t* hits = (uint8_t*)(bin + BL.hits);

@@ -43,7 +43,9 @@
 extern "C" {
 #endif
 
-/* Scratch allocator: must return a device pointer to >= `bytes` bytes, 256-byte aligned. */
+/* Scratch allocator: must return a device pointer to >= `bytes` bytes, 256-byte aligned.  A callback may be invoked more
+ * than once per call (the binning chunk is requested early from an estimate and again if that was too small); only the
+ * pointer returned LAST is used, and the chunk may be larger than the library strictly needs. */
 typedef void* (*gs2d_alloc_fn)(void* user, size_t bytes);
 
 /* Returns num_rendered (>= 0, number of (tile, Gaussian) instances) or < 0 on error.
