@@ -237,7 +237,16 @@ bin_hist_kernel(const uint64_t* __restrict__ keys, int n, int ntiles, uint32_t* 
     __syncthreads();
     const int base = blockIdx.x * BIN_ITEMS;
     const int end = min(n, base + BIN_ITEMS);
-    for (int i = base + threadIdx.x; i < end; i += BIN_T) atomicAdd(&lds[(uint32_t)(keys[i] >> 32)], 1u);
+    // all loads in flight before the first LDS atomic: the kernel is latency-bound, not bandwidth-bound
+    uint32_t tl[BIN_ITEMS / BIN_T];
+#pragma unroll
+    for (int r = 0; r < BIN_ITEMS / BIN_T; r++) {
+        const int i = base + r * BIN_T + threadIdx.x;
+        tl[r] = i < end ? (uint32_t)(keys[i] >> 32) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int r = 0; r < BIN_ITEMS / BIN_T; r++)
+        if (tl[r] != 0xffffffffu) atomicAdd(&lds[tl[r]], 1u);
     __syncthreads();
     for (int t = threadIdx.x; t < ntiles; t += BIN_T) hist[(size_t)t * nblocks + blockIdx.x] = lds[t];
 }
@@ -255,7 +264,19 @@ bin_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restr
     const int wbeg = blockIdx.x * BIN_ITEMS + wave * BIN_WAVE_ITEMS;
     const int wend = min(n, wbeg + BIN_WAVE_ITEMS);
     uint32_t* mine = lds + wave * ntiles;
-    for (int i = wbeg + lane; i < wend; i += 64) atomicAdd(&mine[(uint32_t)(keys_in[i] >> 32)], 1u);
+    // the wave's 1024 pairs live in registers for the whole kernel (one round of loads, issued back to back)
+    constexpr int PER_LANE = BIN_WAVE_ITEMS / 64;  // 16
+    uint64_t k[PER_LANE];
+    uint32_t v[PER_LANE];
+#pragma unroll
+    for (int r = 0; r < PER_LANE; r++) {
+        const int i = wbeg + r * 64 + lane;
+        k[r] = i < wend ? keys_in[i] : ~0ull;
+        v[r] = i < wend ? vals_in[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < PER_LANE; r++)
+        if (wbeg + r * 64 + lane < wend) atomicAdd(&mine[(uint32_t)(k[r] >> 32)], 1u);
     __syncthreads();
     for (int t = threadIdx.x; t < ntiles; t += BIN_T) {
         const size_t hidx = (size_t)t * nblocks + blockIdx.x;
@@ -270,11 +291,11 @@ bin_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restr
     }
     __syncthreads();
     const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    for (int i0 = wbeg; i0 < wend; i0 += 64) {
-        const int i = i0 + lane;
-        const bool valid = i < wend;
-        const uint64_t k = valid ? keys_in[i] : 0ull;
-        const uint32_t d = (uint32_t)(k >> 32);
+#pragma unroll
+    for (int r = 0; r < PER_LANE; r++) {
+        if (wbeg + r * 64 >= wend) break;  // wave-uniform
+        const bool valid = wbeg + r * 64 + lane < wend;
+        const uint32_t d = (uint32_t)(k[r] >> 32);
         uint64_t peers = __ballot(valid);
         for (int b = 0; b < nbits; b++) {
             const uint64_t vote = __ballot((d >> b) & 1u);
@@ -286,8 +307,8 @@ bin_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restr
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             const uint32_t dst = before + (uint32_t)__popcll(peers & lt_mask);
-            keys_out[dst] = k;
-            vals_out[dst] = vals_in[i];
+            keys_out[dst] = k[r];
+            vals_out[dst] = v[r];
         }
     }
 }

@@ -1,5 +1,8 @@
 // Dev tool (not product, not oracle): counts blend-loop trips under different sub-tile queue granularities, from the
 // oracle's forward state.  gcc -O2 -fopenmp -shared -fPIC scripts/dev/trip_sim.c -o /tmp/trip_sim.so
+#ifndef ROWLEVEL
+#define ROWLEVEL 0
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
@@ -38,6 +41,8 @@ void trip_sim(int W, int H, const uint32_t* ranges, const uint32_t* point_list, 
                 last[i] = (x < W && y < H) ? n_contrib[y * W + x] : 0;
                 if (last[i] > qlast) qlast = last[i];
             }
+            uint32_t rowlast[4] = {0, 0, 0, 0};
+            for (int i = 0; i < 64; i++) { int r = (i >> 5 << 1) | ((i & 7) >> 2); if (last[i] > rowlast[r]) rowlast[r] = last[i]; }
             double tot4[4] = {0}, tot2[16] = {0};
             int c2_128[16] = {0};
             for (uint32_t base = s; base < e && (base - s) < qlast; base += 64) {
@@ -46,7 +51,8 @@ void trip_sim(int W, int H, const uint32_t* ranges, const uint32_t* point_list, 
                     uint32_t id = point_list[j];
                     uint64_t m = 0;
                     for (int i = 0; i < 64; i++) {
-                        if (j - s >= last[i]) continue;
+                        if (!ROWLEVEL && j - s >= last[i]) continue;
+                        if (ROWLEVEL && j - s >= rowlast[i >> 5 << 1 | ((i & 7) >> 2)]) continue;
                         int x = qx + (i & 7), y = qy + (i >> 3);
                         if (passes(tm + 9 * id, normal_opacity[4 * id + 3], (float)x, (float)y, means2D[2 * id], means2D[2 * id + 1]))
                             m |= 1ull << i;
