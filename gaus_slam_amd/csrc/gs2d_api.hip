@@ -265,7 +265,7 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
         GS2D_STAGE("ranges");
     }
     if (R > 0) {
-        gs2d::launch_tile_depth_sort(R, IL.tiles, ranges, keys, point_list, keys_alt, vals_alt, s);
+        gs2d::launch_tile_depth_sort(R, IL.tiles, ranges, keys, point_list, keys_alt, vals_alt, one_pass ? 1 : 0, debug ? 1 : 0, s);
         g_timer.end(ST_SORT, s);
         GS2D_STAGE("tile depth sort");
     }

@@ -252,6 +252,7 @@ bin_hist_kernel(const uint64_t* __restrict__ keys, int n, int ntiles, uint32_t* 
 }
 
 // offs_incl = inclusive scan of hist (same indexing).  Stable: element order inside a tile is preserved.
+// Output: packed (depth bits, id) pairs in keys_out's 8-byte slots (vals_out is not written).
 __global__ void __launch_bounds__(BIN_T)
 bin_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
                    uint32_t* __restrict__ vals_out, int n, int ntiles, int nbits, const uint32_t* __restrict__ offs_incl,
@@ -307,8 +308,8 @@ bin_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restr
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             const uint32_t dst = before + (uint32_t)__popcll(peers & lt_mask);
-            keys_out[dst] = k[r];
-            vals_out[dst] = v[r];
+            // one 8-byte store per pair: (depth bits, Gaussian id); the tile id is implied by the position
+            reinterpret_cast<uint2*>(keys_out)[dst] = make_uint2((uint32_t)k[r], v[r]);
         }
     }
 }
@@ -369,41 +370,54 @@ __device__ void sort_segment_by_depth(uint32_t* ka, uint32_t* va, uint32_t* kb, 
     }
 }
 
+// packed != 0: the segment holds (depth bits, id) pairs in the 8-byte key slots (output of bin_scatter_kernel);
+// packed == 0: 64-bit keys + separate ids (output of the generic radix passes).  The sorted ids always land in `vals`
+// (the point list); the full 64-bit keys are materialised only when write_keys != 0 (debug / parity tests).
 __global__ void __launch_bounds__(256)
 tile_depth_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                       uint64_t* __restrict__ keys_alt, uint32_t* __restrict__ vals_alt, int cap)
+                       uint64_t* __restrict__ keys_alt, uint32_t* __restrict__ vals_alt, int cap, int packed, int write_keys)
 {
     extern __shared__ uint32_t dyn[];  // [4][cap]: ka, va, kb, vb
     __shared__ uint32_t wcnt[4][256];
     const int tile = blockIdx.x;
     const uint2 r = ranges[tile];
     const int n = (int)(r.y - r.x);
-    if (n <= 1) return;
+    if (n <= 0) return;
     uint64_t* kseg = keys + r.x;
     uint32_t* vseg = vals + r.x;
+    const uint2* pseg = reinterpret_cast<const uint2*>(kseg);
+    const uint64_t hi = (uint64_t)(uint32_t)tile << 32;
     if (n <= cap) {
         uint32_t *ka = dyn, *va = dyn + cap, *kb = dyn + 2 * cap, *vb = dyn + 3 * cap;
-        for (int i = threadIdx.x; i < n; i += 256) { ka[i] = (uint32_t)kseg[i]; va[i] = vseg[i]; }
+        for (int i = threadIdx.x; i < n; i += 256) {
+            if (packed) { const uint2 p = pseg[i]; ka[i] = p.x; va[i] = p.y; }
+            else { ka[i] = (uint32_t)kseg[i]; va[i] = vseg[i]; }
+        }
         __syncthreads();
-        sort_segment_by_depth(ka, va, kb, vb, n, wcnt);  // 4 passes: result back in ka / va
-        const uint64_t hi = (uint64_t)(uint32_t)tile << 32;
-        for (int i = threadIdx.x; i < n; i += 256) { kseg[i] = hi | ka[i]; vseg[i] = va[i]; }
+        if (n > 1) sort_segment_by_depth(ka, va, kb, vb, n, wcnt);  // 4 passes: result back in ka / va
+        for (int i = threadIdx.x; i < n; i += 256) {
+            vseg[i] = va[i];
+            if (write_keys) kseg[i] = hi | ka[i];
+        }
     } else {
-        // oversized list: same algorithm on global memory; the 32-bit depth keys are packed in place over the first
-        // half of each 64-bit slot array (segment-private scratch), then re-expanded.
-        uint32_t* ka = reinterpret_cast<uint32_t*>(kseg);             // n u32 inside the n u64 slots
-        uint32_t* kb = reinterpret_cast<uint32_t*>(keys_alt + r.x);
-        uint32_t* vb = vals_alt + r.x;
-        // compact depth bits front to back is unsafe in place (slot i/2 is read later), so stage through kb first
-        for (int i = threadIdx.x; i < n; i += 256) kb[i] = (uint32_t)kseg[i];
+        // oversized list: same algorithm on global ping-pong arrays carved from the segment's own scratch slots:
+        // ka, va = the two halves of the segment's keys_alt slots, kb = its vals_alt slots, vb = its point-list slots
+        uint32_t* ka = reinterpret_cast<uint32_t*>(keys_alt + r.x);
+        uint32_t* va = ka + n;
+        uint32_t* kb = vals_alt + r.x;
+        uint32_t* vb = vseg;
+        if (packed) {
+            for (int i = threadIdx.x; i < n; i += 256) { const uint2 p = pseg[i]; ka[i] = p.x; va[i] = p.y; }
+        } else {
+            // vseg doubles as vb, so the ids are copied out first
+            for (int i = threadIdx.x; i < n; i += 256) { ka[i] = (uint32_t)kseg[i]; va[i] = vseg[i]; }
+        }
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += 256) ka[i] = kb[i];
-        __syncthreads();
-        sort_segment_by_depth(ka, vseg, kb, vb, n, wcnt);
-        for (int i = threadIdx.x; i < n; i += 256) kb[i] = ka[i];
-        __syncthreads();
-        const uint64_t hi = (uint64_t)(uint32_t)tile << 32;
-        for (int i = threadIdx.x; i < n; i += 256) kseg[i] = hi | kb[i];
+        sort_segment_by_depth(ka, va, kb, vb, n, wcnt);  // even number of passes: result in ka / va
+        for (int i = threadIdx.x; i < n; i += 256) {
+            vseg[i] = va[i];
+            if (write_keys) kseg[i] = hi | ka[i];
+        }
     }
 }
 
@@ -480,7 +494,7 @@ bool launch_bin_by_tile(int R, int tiles, int nbits, const uint64_t* keys_in, co
 }
 
 void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt,
-                            uint32_t* vals_alt, hipStream_t s)
+                            uint32_t* vals_alt, int packed, int write_keys, hipStream_t s)
 {
     if (R <= 0 || tiles <= 0) return;
     // LDS capacity per tile: 1536, 2048 or 4096 elements (16 B each, <= 64 KB dynamic LDS), at least ~1.3x the mean
@@ -489,7 +503,7 @@ void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* key
     const int avg = R / tiles;
     const int cap = avg > 1300 ? 4096 : (avg > 1180 ? 2048 : 1536);
     hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(tiles), dim3(256), (size_t)cap * 16, s, ranges, keys, vals, keys_alt,
-                       vals_alt, cap);
+                       vals_alt, cap, packed, write_keys);
 }
 
 void launch_tile_ranges(int R, const uint64_t* keys, uint2* ranges, int tiles, hipStream_t s)

@@ -132,13 +132,16 @@ void launch_duplicate(int P, const float4* rec, const float* depths, const uint3
 // the unsorted input must sit in the "b" buffers when the pass count ceil((end-begin)/8) is odd, else in "a".
 void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int begin_bit,
                        int end_bit, uint32_t* hist, size_t hist_elems, hipStream_t s);
-// single-pass stable counting sort of the pairs by tile id (key >> 32) that also writes the tile ranges;
+// single-pass stable counting sort of the pairs by tile id (key >> 32) that also writes the tile ranges; the output is
+// PACKED: keys_out[i] = id << 32 | depth bits (vals_out untouched);
 // returns false (nothing launched) when there are more than GS2D_BIN_MAX_TILES tiles
 bool launch_bin_by_tile(int R, int tiles, int nbits, const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out,
                         uint32_t* vals_out, uint32_t* hist, uint2* ranges, hipStream_t s);
-// one workgroup per tile: stable sort of the tile's segment by the low 32 key bits (depth), in LDS
+// one workgroup per tile: stable sort of the tile's segment by the 32 depth bits, in LDS.  packed: the segment holds
+// (depth, id) pairs as written by launch_bin_by_tile (else 64-bit keys + ids); the sorted ids land in `vals`, the full
+// 64-bit keys are written back only if write_keys
 void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt,
-                            uint32_t* vals_alt, hipStream_t s);
+                            uint32_t* vals_alt, int packed, int write_keys, hipStream_t s);
 void launch_tile_ranges(int R, const uint64_t* keys, uint2* ranges, int tiles, hipStream_t s);
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
                       const float* bg, float* out_color, float* out_others, float* pix_state, uint8_t* hits, int use_sa,

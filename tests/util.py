@@ -75,7 +75,16 @@ def hip_forward(sc, use_sa=True, bg=(0.0, 0.0, 0.0), shs=None, sh_degree=0, tran
         out["rec"] = view(g, go[3], np.float32, P * 20).reshape(P, 20)
         out["clamped"] = view(g, go[4], np.uint8, P * 3).reshape(P, 3)
         out["point_list"] = view(b, bo[0], np.uint32, R) if R > 0 else np.zeros(0, np.uint32)
-        out["keys"] = view(b, bo[1], np.uint64, R) if R > 0 else np.zeros(0, np.uint64)
+        # the full 64-bit sorted keys are materialised only in debug mode (the product path keeps packed (depth, id)
+        # pairs and writes just the point list): fetch them from a second, debug-mode forward of the same inputs
+        if R > 0 and not debug:
+            dbg_args = args[:-1] + (True,)
+            R2, _, _, _, _, binning2, _ = rasterizer.rasterize_gaussians(*dbg_args)
+            torch.cuda.synchronize()
+            assert R2 == R
+            out["keys"] = view(binning2.cpu().numpy(), bo[1], np.uint64, R)
+        else:
+            out["keys"] = view(b, bo[1], np.uint64, R) if R > 0 else np.zeros(0, np.uint64)
         out["ranges"] = view(im, io[0], np.uint32, gx * gy * 2).reshape(gx * gy, 2)
         plane = gx * gy * 256
         ps = view(im, io[1], np.float32, 7 * plane).reshape(7, plane)
