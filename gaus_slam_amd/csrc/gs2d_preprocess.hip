@@ -313,10 +313,13 @@ preprocess_bwd_one(int idx, int P, int D, int M, const float* __restrict__ means
         // culled in the forward: every gradient is exactly zero (the reference gets this from torch::zeros,
         // rasterize_points.cu:192-200; here the kernel writes it so the caller can hand in uninitialised memory)
 #pragma unroll
-        for (int i = 0; i < 3; i++) { dL_dcolor[3 * idx + i] = 0.f; dL_dnormal[3 * idx + i] = 0.f; dL_dmean2D[3 * idx + i] = 0.f; dL_dmean3D[3 * idx + i] = 0.f; }
+        for (int i = 0; i < 3; i++) { dL_dcolor[3 * idx + i] = 0.f; dL_dmean2D[3 * idx + i] = 0.f; dL_dmean3D[3 * idx + i] = 0.f; }
+        if (dL_dnormal) for (int i = 0; i < 3; i++) dL_dnormal[3 * idx + i] = 0.f;
         dL_dopacity[idx] = 0.f;
+        if (dL_dtransMat) {
 #pragma unroll
-        for (int i = 0; i < 9; i++) dL_dtransMat[9 * (size_t)idx + i] = 0.f;
+            for (int i = 0; i < 9; i++) dL_dtransMat[9 * (size_t)idx + i] = 0.f;
+        }
         dL_dscale[2 * idx] = 0.f; dL_dscale[2 * idx + 1] = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; i++) dL_drot[4 * idx + i] = 0.f;
@@ -334,7 +337,7 @@ preprocess_bwd_one(int idx, int P, int D, int M, const float* __restrict__ means
     // unpack the blend-stage gradients into the public tensors
     float dcol[3] = {g[0], g[1], g[2]};
     dL_dcolor[3 * idx] = dcol[0]; dL_dcolor[3 * idx + 1] = dcol[1]; dL_dcolor[3 * idx + 2] = dcol[2];
-    dL_dnormal[3 * idx] = g[3]; dL_dnormal[3 * idx + 1] = g[4]; dL_dnormal[3 * idx + 2] = g[5];
+    if (dL_dnormal) { dL_dnormal[3 * idx] = g[3]; dL_dnormal[3 * idx + 1] = g[4]; dL_dnormal[3 * idx + 2] = g[5]; }
     dL_dopacity[idx] = g[15];
     float dT[9];
 #pragma unroll
@@ -456,8 +459,10 @@ preprocess_bwd_one(int idx, int P, int D, int M, const float* __restrict__ means
 #pragma unroll
         for (int i = 0; i < 4; i++) dL_drot[4 * idx + i] = 0.f;
     }
+    if (dL_dtransMat) {
 #pragma unroll
-    for (int i = 0; i < 9; i++) dL_dtransMat[9 * (size_t)idx + i] = dTout[i];
+        for (int i = 0; i < 9; i++) dL_dtransMat[9 * (size_t)idx + i] = dTout[i];
+    }
     // densification hack, backward.cu:660-663 (double arithmetic as written in the reference)
     const float depth = q2.z;
     dL_dmean2D[3 * idx + 0] = (float)((double)(dTout[2] * depth) * 0.5 * (double)(float)cam.W);

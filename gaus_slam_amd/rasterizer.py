@@ -117,13 +117,15 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, use_sa,
-                                 debug, pose_Rt=None, pose_quat=None, grad_sink=None):
+                                 debug, pose_Rt=None, pose_quat=None, grad_sink=None, lean=False):
     """_C.rasterize_gaussians_backward (rasterize_points.cu:140-239): returns
     (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dtransMat[P,9], dL_dsh[P,M,3],
      dL_dscales[P,2], dL_drotations[P,4]).
     grad_sink (optional): dict with any of means3D / opacities / scales / rotations / colors -> contiguous fp32 tensor of
     the gradient's shape; the kernels then write those gradients there (e.g. straight into the all-reduce bucket) instead
-    of into fresh tensors."""
+    of into fresh tensors.
+    lean (used by the autograd node): skip the outputs nobody can observe there -- the internal dL_dnormal and, when no
+    cov3D_precomp was given, dL_dtransMat (returned as None): 48 B per Gaussian less to write."""
     for name, t in (("background", background), ("means3D", means3D), ("radii", radii), ("colors", colors),
                     ("scales", scales), ("rotations", rotations), ("transMat_precomp", transMat_precomp),
                     ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("sh", sh), ("campos", campos),
@@ -138,6 +140,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     z = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dnormal = z(P, 3), z(P, 3), z(P, NUM_CHANNELS), z(P, 3)
     dL_dopacity, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations = z(P, 1), z(P, 9), z(P, M, 3), z(P, 2), z(P, 4)
+    if lean:
+        dL_dnormal = None
+        if transMat_precomp.numel() == 0:
+            dL_dtransMat = None
     if grad_sink:
         def sunk(name, t):
             s = grad_sink.get(name)
@@ -161,8 +167,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 P, int(degree), M, int(R), _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(sc_),
                 float(scale_modifier), _ptr(rot_), _ptr(tm_), _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx),
                 float(tan_fovy), radii_.data_ptr(), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
-                dc_.data_ptr(), do_.data_ptr(), dL_dmeans2D.data_ptr(), dL_dnormal.data_ptr(), dL_dopacity.data_ptr(),
-                dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dtransMat.data_ptr(), _ptr(dL_dsh),
+                dc_.data_ptr(), do_.data_ptr(), dL_dmeans2D.data_ptr(), _ptr(dL_dnormal), dL_dopacity.data_ptr(),
+                dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), _ptr(dL_dtransMat), _ptr(dL_dsh),
                 dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(use_sa)), int(bool(debug)), _ptr(prt_),
                 _ptr(pq_), _ptr(dL_dpose), _stream_ptr(dev))
         if rc < 0:
@@ -238,7 +244,7 @@ class _RasterizeGaussians(torch.autograd.Function):
          grad_rotations) = rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, sh, rs.sh_degree, rs.campos, geomBuffer,
-            ctx.num_rendered, binningBuffer, imgBuffer, rs.use_sa, rs.debug, grad_sink=sink)
+            ctx.num_rendered, binningBuffer, imgBuffer, rs.use_sa, rs.debug, grad_sink=sink, lean=True)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
                 grad_cov3Ds_precomp, None)
 

@@ -56,7 +56,7 @@ class _RasterizeTracking(torch.autograd.Function):
         (g_means2D, g_colors, g_opac, g_means3D, g_T, g_sh, g_scales, g_rot, g_pose) = _r.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix,
             rs.tanfovx, rs.tanfovy, grad_color, grad_allmap, e, rs.sh_degree, rs.campos, geom, ctx.num_rendered, binning,
-            img, rs.use_sa, rs.debug, pose_Rt=pose_Rt, pose_quat=pose_q)
+            img, rs.use_sa, rs.debug, pose_Rt=pose_Rt, pose_quat=pose_q, lean=True)
         g_w2c = torch.zeros((4, 4), dtype=torch.float32, device=means3D.device)
         g_w2c[:3, :4] = g_pose
         # rotations are detached in the reference's tracking / BA renderers (render/__init__.py:36,98)

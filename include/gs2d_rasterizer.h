@@ -91,11 +91,11 @@ int gs2d_backward(
     const float* dL_dpix,             /* [3,H,W] */
     const float* dL_depths,           /* [7,H,W] */
     float* dL_dmean2D,                /* [P,3] */
-    float* dL_dnormal,                /* [P,3] */
+    float* dL_dnormal,                /* [P,3] or NULL: internal in the reference (never returned to Python) */
     float* dL_dopacity,               /* [P]   */
     float* dL_dcolor,                 /* [P,3] */
     float* dL_dmean3D,                /* [P,3] */
-    float* dL_dtransMat,              /* [P,9] */
+    float* dL_dtransMat,              /* [P,9] or NULL when the caller has no use for it (no cov3D_precomp input) */
     float* dL_dsh,                    /* [P,M,3] */
     float* dL_dscale,                 /* [P,2] */
     float* dL_drot,                   /* [P,4] */
