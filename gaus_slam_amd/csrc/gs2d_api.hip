@@ -178,11 +178,12 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
 
     g_timer.begin(ST_PREPROCESS, s);
     gs2d::launch_preprocess_fwd(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, transMat_precomp,
-                                colors_precomp, cam, radii, depths, rec, tiles_touched, clamped, pose_Rt, pose_quat, s);
+                                colors_precomp, cam, radii, depths, rec, tiles_touched, clamped, pose_Rt, pose_quat, scan_tmp,
+                                s);
     g_timer.end(ST_PREPROCESS, s);
     GS2D_STAGE("preprocess");
 
-    const int nblk = (P + GS2D_SCAN_ITEMS - 1) / GS2D_SCAN_ITEMS;
+    const int nblk = (P + 255) / 256;  // scan_tmp[0..nblk) = per-workgroup sums, then exclusive block offsets
     uint32_t* total_dev = scan_tmp + nblk + 8;
     // The one host sync of the forward (rasterizer_impl.cu:287): the binning chunk is sized by num_rendered.
     // Read-back without an OS-level wait and without a copy: the scan stores the total straight into a pinned host word
@@ -194,7 +195,7 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     volatile uint32_t* pinned = g_pinned.p;
     *pinned = 0xFFFFFFFFu;
     g_timer.begin(ST_SCAN, s);
-    gs2d::launch_inclusive_scan(tiles_touched, point_offsets, P, scan_tmp, total_dev, s, g_pinned.p);
+    gs2d::launch_offsets_blocksums(P, scan_tmp, total_dev, g_pinned.p, s);
     g_timer.end(ST_SCAN, s);
     GS2D_STAGE("scan");
 
@@ -242,14 +243,16 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     const int end_bit = 32 + tile_bits;
     const bool one_pass = IL.tiles <= GS2D_BIN_MAX_TILES;
     const int passes = one_pass ? 1 : (end_bit - 32 + 7) / 8;
+    // unsorted pairs go where the ping-pong needs them so that the result lands in (keys, point_list)
+    uint64_t* k_unsorted = (passes & 1) ? keys_alt : keys;
+    uint32_t* v_unsorted = (passes & 1) ? vals_alt : point_list;
+    // always launched: it also completes point_offsets (all zeros when nothing is visible)
+    g_timer.begin(ST_DUPLICATE, s);
+    gs2d::launch_duplicate(P, rec, depths, tiles_touched, scan_tmp, point_offsets, radii, cam.gx, cam.gy, k_unsorted,
+                           v_unsorted, s);
+    g_timer.end(ST_DUPLICATE, s);
+    GS2D_STAGE("duplicate");
     if (R > 0) {
-        // unsorted pairs go where the ping-pong needs them so that the result lands in (keys, point_list)
-        uint64_t* k_unsorted = (passes & 1) ? keys_alt : keys;
-        uint32_t* v_unsorted = (passes & 1) ? vals_alt : point_list;
-        g_timer.begin(ST_DUPLICATE, s);
-        gs2d::launch_duplicate(P, rec, depths, point_offsets, radii, cam.gx, cam.gy, k_unsorted, v_unsorted, s);
-        g_timer.end(ST_DUPLICATE, s);
-        GS2D_STAGE("duplicate");
         g_timer.begin(ST_SORT, s);
         if (one_pass) {
             gs2d::launch_bin_by_tile(R, IL.tiles, tile_bits, k_unsorted, v_unsorted, keys, point_list, hist, ranges, s);

@@ -109,14 +109,22 @@ __device__ __forceinline__ int f2i_sat(float v)
 
 // rasterizer_impl.cu:70-111; one thread per Gaussian, tiles emitted row-major (y outer, x inner).
 __global__ void __launch_bounds__(256)
-duplicate_kernel(int P, const float4* __restrict__ rec, const float* __restrict__ depths, const uint32_t* __restrict__ offsets,
-                 const int* __restrict__ radii, int gx, int gy, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+duplicate_kernel(int P, const float4* __restrict__ rec, const float* __restrict__ depths,
+                 const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_offsets,
+                 uint32_t* __restrict__ point_offsets, const int* __restrict__ radii, int gx, int gy,
+                 uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
+    // The prefix sum of tiles_touched (rasterizer_impl.cu:283) is finished here: the preprocess kernel left one sum per
+    // 256 Gaussians, scan_blocksums_kernel turned those into exclusive block offsets, and this workgroup (the same 256
+    // Gaussians) adds its own inclusive scan -- no separate scan-apply launch.
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t mine = idx < P ? tiles_touched[idx] : 0u;
+    const uint32_t incl = block_offsets[blockIdx.x] + block_incl_scan(mine, nullptr);
     if (idx >= P) return;
+    point_offsets[idx] = incl;  // inclusive offsets, as the reference's InclusiveSum leaves them
     const int rad = radii[idx];
     if (rad <= 0) return;
-    uint32_t off = idx == 0 ? 0u : offsets[idx - 1];
+    uint32_t off = incl - mine;
     const float px = rec[(size_t)idx * GS2D_REC_F4 + 0].w, py = rec[(size_t)idx * GS2D_REC_F4 + 1].w;
     const float r = (float)rad;
     const int minx = min(gx, max(0, f2i_sat((px - r) / (float)GS2D_TILE)));
@@ -449,11 +457,17 @@ void launch_inclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* t
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(SCAN_T), 0, s, in, out, n, tmp);
 }
 
-void launch_duplicate(int P, const float4* rec, const float* depths, const uint32_t* offsets, const int* radii,
-                      int gx, int gy, uint64_t* keys, uint32_t* vals, hipStream_t s)
+void launch_offsets_blocksums(int P, uint32_t* block_sums, uint32_t* total_dev, uint32_t* total_host, hipStream_t s)
 {
-    hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, rec, depths, offsets, radii, gx, gy,
-                       keys, vals);
+    hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_T), 0, s, block_sums, (P + 255) / 256, total_dev, total_host);
+}
+
+void launch_duplicate(int P, const float4* rec, const float* depths, const uint32_t* tiles_touched,
+                      const uint32_t* block_offsets, uint32_t* point_offsets, const int* radii, int gx, int gy,
+                      uint64_t* keys, uint32_t* vals, hipStream_t s)
+{
+    hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, rec, depths, tiles_touched, block_offsets,
+                       point_offsets, radii, gx, gy, keys, vals);
 }
 
 void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int begin_bit,

@@ -56,7 +56,7 @@ static inline GeomLayout geom_layout(int P)
     L.point_offsets = o; o = gs2d_align_up(o + 4 * p, 256);
     L.rec = o; o = gs2d_align_up(o + 4 * GS2D_REC_FLOATS * p, 256);
     L.clamped = o; o = gs2d_align_up(o + 3 * p, 256);
-    const size_t nblk = (p + GS2D_SCAN_ITEMS - 1) / GS2D_SCAN_ITEMS;
+    const size_t nblk = (p + 255) / 256;  // one tiles_touched sum per preprocess workgroup (256 Gaussians)
     L.scan_tmp = o; o = gs2d_align_up(o + 4 * (nblk + 64), 256);
     // backward-time accumulator (the reference backward has no allocator callback, so it is reserved here)
     L.grad_rec = o; o = gs2d_align_up(o + 4 * GS2D_GRAD_FLOATS * p, 256);
@@ -114,7 +114,7 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
                            const float* rotations, const float* opacities, const float* shs,
                            const float* transMat_precomp, const float* colors_precomp, const CamParams& cam,
                            int* radii, float* depths, float4* rec, uint32_t* tiles_touched, uint8_t* clamped,
-                           const float* pose_Rt, const float* pose_q, hipStream_t s);
+                           const float* pose_Rt, const float* pose_q, uint32_t* block_sums, hipStream_t s);
 void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float4* rec, const int* radii,
                            const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
                            const CamParams& cam, const float* grad_rec, float* dL_dtransMat, float* dL_dnormal,
@@ -126,8 +126,13 @@ void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* 
 // total_host (optional): pinned host word that receives the total with a system-scope store as soon as it is known.
 void launch_inclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* tmp, uint32_t* total_out, hipStream_t s,
                            uint32_t* total_host = nullptr);
-void launch_duplicate(int P, const float4* rec, const float* depths, const uint32_t* offsets, const int* radii,
-                      int gx, int gy, uint64_t* keys, uint32_t* vals, hipStream_t s);
+// prefix sum of tiles_touched in three fused steps: launch_preprocess_fwd leaves one sum per 256 Gaussians in
+// block_sums; launch_offsets_blocksums scans them in place (exclusive) and publishes the total (device word + optional
+// pinned host word, system-scope store); launch_duplicate adds each block's own scan and writes point_offsets.
+void launch_offsets_blocksums(int P, uint32_t* block_sums, uint32_t* total_dev, uint32_t* total_host, hipStream_t s);
+void launch_duplicate(int P, const float4* rec, const float* depths, const uint32_t* tiles_touched,
+                      const uint32_t* block_offsets, uint32_t* point_offsets, const int* radii, int gx, int gy,
+                      uint64_t* keys, uint32_t* vals, hipStream_t s);
 // stable LSD radix sort of (u64 key, u32 val) pairs on key bits [begin_bit, end_bit). Result lands in keys_a/vals_a;
 // the unsorted input must sit in the "b" buffers when the pass count ceil((end-begin)/8) is odd, else in "a".
 void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int begin_bit,

@@ -153,23 +153,27 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       const float* __restrict__ shs, const float* __restrict__ transMat_precomp,
                       const float* __restrict__ colors_precomp, const CamParams cam, int* __restrict__ radii,
                       float* __restrict__ depths, float4* __restrict__ rec, uint32_t* __restrict__ tiles_touched,
-                      uint8_t* __restrict__ clamped, const float* __restrict__ pose_Rt, const float* __restrict__ pose_q)
+                      uint8_t* __restrict__ clamped, const float* __restrict__ pose_Rt, const float* __restrict__ pose_q,
+                      uint32_t* __restrict__ block_sums)
 {
+    __shared__ uint32_t wave_tiles[4];
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
+    const bool valid = idx < P;
     // forward.cu:183-184: invisible unless proven otherwise
     int out_radius = 0;
     uint32_t out_tiles = 0;
     float out_depth = 0.f;
     float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0, r4 = r0;
 
-    float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (valid) { px = means3D[3 * idx]; py = means3D[3 * idx + 1]; pz = means3D[3 * idx + 2]; }
     if (pose_Rt != nullptr) pose_point(pose_Rt, px, py, pz);
     const float* vm = cam.vm;
     const float pvx = ((vm[0] * px + vm[4] * py) + vm[8] * pz) + vm[12];
     const float pvy = ((vm[1] * px + vm[5] * py) + vm[9] * pz) + vm[13];
     const float pvz = ((vm[2] * px + vm[6] * py) + vm[10] * pz) + vm[14];
     do {
+        if (!valid) break;
         if (pvz <= 0.2f) break;  // auxiliary.h:199
         float T[9], normal[3];
         if (transMat_precomp == nullptr) {
@@ -222,11 +226,20 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         const float rho_max = opa > 0.f ? 2.0f * logf(255.0f * opa) * 1.0001f + 1e-3f : (opa == opa ? -1.f : 1e30f);
         r4 = make_float4(col[1], col[2], rho_max, 0.f);
     } while (0);
-    radii[idx] = out_radius;
-    tiles_touched[idx] = out_tiles;
-    depths[idx] = out_depth;
-    float4* rp = rec + (size_t)idx * GS2D_REC_F4;
-    rp[0] = r0; rp[1] = r1; rp[2] = r2; rp[3] = r3; rp[4] = r4;
+    if (valid) {
+        radii[idx] = out_radius;
+        tiles_touched[idx] = out_tiles;
+        depths[idx] = out_depth;
+        float4* rp = rec + (size_t)idx * GS2D_REC_F4;
+        rp[0] = r0; rp[1] = r1; rp[2] = r2; rp[3] = r3; rp[4] = r4;
+    }
+    // first step of the prefix sum over tiles_touched: this workgroup's total (see launch_duplicate)
+    uint32_t tsum = out_tiles;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tsum += (uint32_t)__shfl_xor((int)tsum, d, 64);
+    if ((threadIdx.x & 63) == 0) wave_tiles[threadIdx.x >> 6] = tsum;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = (wave_tiles[0] + wave_tiles[1]) + (wave_tiles[2] + wave_tiles[3]);
 }
 
 // backward.cu:20-139
@@ -526,11 +539,11 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
                            const float* rotations, const float* opacities, const float* shs,
                            const float* transMat_precomp, const float* colors_precomp, const CamParams& cam,
                            int* radii, float* depths, float4* rec, uint32_t* tiles_touched, uint8_t* clamped,
-                           const float* pose_Rt, const float* pose_q, hipStream_t s)
+                           const float* pose_Rt, const float* pose_q, uint32_t* block_sums, hipStream_t s)
 {
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, transMat_precomp, colors_precomp, cam, radii, depths,
-                       rec, tiles_touched, clamped, pose_Rt, pose_q);
+                       rec, tiles_touched, clamped, pose_Rt, pose_q, block_sums);
 }
 
 void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float4* rec, const int* radii,
