@@ -26,10 +26,10 @@ void trip_sim(int W, int H, const uint32_t* ranges, const uint32_t* point_list, 
               const float* normal_opacity, const uint32_t* n_contrib, double* out)
 {
     int gx = (W + 15) / 16, gy = (H + 15) / 16;
-    double acc[10] = {0};
+    double acc[10] = {0}; double accx = 0;
 #pragma omp parallel for schedule(dynamic, 4)
     for (int t = 0; t < gx * gy; t++) {
-        double loc[10] = {0};
+        double loc[10] = {0}; double locx = 0;
         int tx = t % gx, ty = t / gx;
         uint32_t s = ranges[2 * t], e = ranges[2 * t + 1];
         for (int q = 0; q < 4; q++) {
@@ -45,6 +45,7 @@ void trip_sim(int W, int H, const uint32_t* ranges, const uint32_t* point_list, 
             for (int i = 0; i < 64; i++) { int r = (i >> 5 << 1) | ((i & 7) >> 2); if (last[i] > rowlast[r]) rowlast[r] = last[i]; }
             double tot4[4] = {0}, tot2[16] = {0};
             int c2_128[16] = {0};
+            int cb4[4] = {0}, cb_fill = 0; double cb_trips = 0;
             for (uint32_t base = s; base < e && (base - s) < qlast; base += 64) {
                 int c4[4] = {0}, c2[16] = {0}, c8 = 0;
                 for (uint32_t j = base; j < e && j < base + 64; j++) {
@@ -71,6 +72,9 @@ void trip_sim(int W, int H, const uint32_t* ranges, const uint32_t* point_list, 
                         if (m & gm) c2[g]++;
                     }
                 }
+                /* compacted batches: close the batch if this chunk's touched splats do not fit in 64 slots */
+                if (cb_fill + c8 > 64) { int mm = 0; for (int r = 0; r < 4; r++) { if (cb4[r] > mm) mm = cb4[r]; cb4[r] = 0; } cb_trips += mm; cb_fill = 0; }
+                cb_fill += c8; for (int r = 0; r < 4; r++) cb4[r] += c4[r];
                 int m4 = 0, m2 = 0;
                 for (int r = 0; r < 4; r++) { if (c4[r] > m4) m4 = c4[r]; loc[4] += 16.0 * c4[r]; tot4[r] += c4[r]; }
                 for (int g = 0; g < 16; g++) { if (c2[g] > m2) m2 = c2[g]; loc[5] += 4.0 * c2[g]; tot2[g] += c2[g]; c2_128[g] += c2[g]; }
@@ -81,13 +85,16 @@ void trip_sim(int W, int H, const uint32_t* ranges, const uint32_t* point_list, 
                     loc[8] += mm;
                 }
             }
+            { int mm = 0; for (int r = 0; r < 4; r++) if (cb4[r] > mm) mm = cb4[r]; cb_trips += mm; }
+            loc[8] = loc[8] * 0 + loc[8]; loc[9] += 0; loc[5] += 0; loc[4] += 0; loc[3] += 0; loc[2] += 0; loc[1] += 0; loc[0] += 0; loc[7] += 0; loc[6] += 0;
+            locx += cb_trips;
             double d4 = 0, d2 = 0;
             for (int r = 0; r < 4; r++) if (tot4[r] > d4) d4 = tot4[r];
             for (int g = 0; g < 16; g++) if (tot2[g] > d2) d2 = tot2[g];
             loc[2] += d4; loc[3] += d2;
         }
 #pragma omp critical
-        for (int i = 0; i < 10; i++) acc[i] += loc[i];
+        { for (int i = 0; i < 10; i++) acc[i] += loc[i]; accx += locx; }
     }
-    memcpy(out, acc, sizeof(acc));
+    memcpy(out, acc, sizeof(acc)); out[10] = accx;
 }
