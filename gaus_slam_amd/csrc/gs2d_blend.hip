@@ -159,7 +159,9 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// dev-only experiment hooks (scripts/dev/variants.sh); empty in the product build
+// Dev-only experiment hooks (scripts/dev/variants.sh builds variants with -DGS2D_EXPERIMENT=n; results are WRONG by
+// design, they only price one ingredient of blend_bwd via scripts/dev/stage_ms.py).  All pass-through in the product
+// build.  1: no global atomics in the flush   2: no butterfly   4: no flush loop   5: plain LDS store instead of ds_add_f32
 #if defined(GS2D_EXPERIMENT) && GS2D_EXPERIMENT == 1
 #define GS2D_EXP_ATOMIC(X) if (va == 123.456f) grad_rec[flush_off] = vb;
 #else
