@@ -72,11 +72,14 @@ __device__ __forceinline__ double block_sum(double v, double* red)
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// acc[0] = sum |c - gt| over the colour mask, acc[1] = sum |d - gt| over its mask, acc[2] = sum dist over the colour
-// mask, acc[3] = #colour-mask pixels, acc[4] = #depth-mask pixels  (doubles: order-independent to ~1e-16)
+// Pass 1: per-block partial sums, partial[b*5 + k] with k = 0: sum |c - gt| over the colour mask, 1: sum |d - gt| over
+// its mask, 2: sum dist over the colour mask, 3: #colour-mask pixels, 4: #depth-mask pixels  (doubles; no atomics: a few
+// hundred blocks hammering five addresses cost 50 us, the per-block partials are re-reduced by every block of pass 2).
+constexpr int LOSS_MAX_BLOCKS = 256;
+
 __global__ void __launch_bounds__(256)
 loss_reduce_kernel(LossCfg L, int HWi, const float* __restrict__ color, const float* __restrict__ allmap,
-                   const float* __restrict__ gt_color, const float* __restrict__ gt_depth, double* __restrict__ acc)
+                   const float* __restrict__ gt_color, const float* __restrict__ gt_depth, double* __restrict__ partial)
 {
     __shared__ double red[4];
     const size_t HW = (size_t)HWi;
@@ -95,16 +98,21 @@ loss_reduce_kernel(LossCfg L, int HWi, const float* __restrict__ color, const fl
     const double v[5] = {sc, sd, sdist, nc, nd};
     for (int i = 0; i < 5; i++) {
         const double s = block_sum(v[i], red);
-        if (threadIdx.x == 0 && s != 0.0) atomicAdd(acc + i, s);
+        if (threadIdx.x == 0) partial[blockIdx.x * 5 + i] = s;
     }
 }
 
+// Pass 2: every block first folds the (<= 256) per-block partials into the five totals, then writes the gradients of
+// its pixels; block 0 also writes the loss.
 __global__ void __launch_bounds__(256)
-loss_grad_kernel(LossCfg L, int HWi, const float* __restrict__ color, const float* __restrict__ allmap,
-                 const float* __restrict__ gt_color, const float* __restrict__ gt_depth, const double* __restrict__ acc,
+loss_grad_kernel(LossCfg L, int HWi, int nparts, const float* __restrict__ color, const float* __restrict__ allmap,
+                 const float* __restrict__ gt_color, const float* __restrict__ gt_depth, const double* __restrict__ partial,
                  float* __restrict__ loss_out, float* __restrict__ dL_dcolor, float* __restrict__ dL_dallmap)
 {
+    __shared__ double red[4];
     const size_t HW = (size_t)HWi;
+    double acc[5];
+    for (int i = 0; i < 5; i++) acc[i] = block_sum((int)threadIdx.x < nparts ? partial[threadIdx.x * 5 + i] : 0.0, red);
     const double nc = acc[3], nd = acc[4];
     float gc_scale, gd_scale, gdist_scale;
     if (L.mode == 0) { gc_scale = L.w_color; gd_scale = L.w_depth; gdist_scale = 0.f; }
@@ -148,7 +156,7 @@ loss_grad_kernel(LossCfg L, int HWi, const float* __restrict__ color, const floa
 extern "C" int gs2d_slam_loss(int mode, int width, int height, const float* color, const float* allmap,
                               const float* gt_color_hwc, const float* gt_depth, float w_color, float w_depth, float w_dist,
                               float silmask_th, float edge_thres, int use_edge_growth, int use_weight_norm, float eps,
-                              float depth_near, float depth_far, double* workspace /* >= 8 doubles */, float* loss_out /* [8] */,
+                              float depth_near, float depth_far, double* workspace /* >= GS2D_LOSS_WS_DOUBLES doubles */, float* loss_out /* [8] */,
                               float* dL_dcolor, float* dL_dallmap, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
@@ -158,10 +166,12 @@ extern "C" int gs2d_slam_loss(int mode, int width, int height, const float* colo
     L.w_color = w_color; L.w_depth = w_depth; L.w_dist = w_dist; L.silmask_th = silmask_th; L.edge_thres = edge_thres;
     L.eps = eps; L.depth_near = depth_near; L.depth_far = depth_far;
     const int HW = width * height;
-    const int grid = (HW + 255) / 256 < 1024 ? (HW + 255) / 256 : 1024;
-    if (hipMemsetAsync(workspace, 0, 8 * sizeof(double), s) != hipSuccess) return -1;
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(grid), dim3(256), 0, s, L, HW, color, allmap, gt_color_hwc, gt_depth, workspace);
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(grid), dim3(256), 0, s, L, HW, color, allmap, gt_color_hwc, gt_depth, workspace,
-                       loss_out, dL_dcolor, dL_dallmap);
+    const int blocks = (HW + 255) / 256;
+    const int rgrid = blocks < LOSS_MAX_BLOCKS ? blocks : LOSS_MAX_BLOCKS;  // one partial per reduce block, <= 256
+    const int ggrid = blocks < 2048 ? blocks : 2048;
+    static_assert(LOSS_MAX_BLOCKS * 5 <= GS2D_LOSS_WS_DOUBLES, "workspace too small");
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(rgrid), dim3(256), 0, s, L, HW, color, allmap, gt_color_hwc, gt_depth, workspace);
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(ggrid), dim3(256), 0, s, L, HW, rgrid, color, allmap, gt_color_hwc, gt_depth,
+                       workspace, loss_out, dL_dcolor, dL_dallmap);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -22,7 +22,7 @@ class _SlamLoss(torch.autograd.Function):
         color_, allmap_ = color.detach().float().contiguous(), allmap.detach().float().contiguous()
         gtc = gt_color.detach().float().contiguous().reshape(H, W, 3)
         gtd = gt_depth.detach().float().contiguous().reshape(H, W)
-        ws = torch.empty(8, dtype=torch.float64, device=dev)
+        ws = torch.empty(1280, dtype=torch.float64, device=dev)  # GS2D_LOSS_WS_DOUBLES
         out = torch.empty(8, dtype=torch.float32, device=dev)
         g_color, g_allmap = torch.empty_like(color_), torch.empty_like(allmap_)
         with torch.cuda.device(dev):

@@ -145,10 +145,12 @@ int sknn_dist2(int N, const float* points, float* out,
  * depth sum, dist sum, #colour-mask, #depth-mask) and the gradients of the loss w.r.t. color / allmap.
  * Default-configuration losses only (no normal loss, no outlier rejection, no exposure).
  */
+#define GS2D_LOSS_WS_DOUBLES 1280
 int gs2d_slam_loss(int mode, int width, int height, const float* color, const float* allmap, const float* gt_color_hwc,
                    const float* gt_depth, float w_color, float w_depth, float w_dist, float silmask_th, float edge_thres,
                    int use_edge_growth, int use_weight_norm, float eps, float depth_near, float depth_far,
-                   double* workspace /* >= 8 doubles */, float* loss_out /* [8] */, float* dL_dcolor, float* dL_dallmap,
+                   double* workspace /* >= GS2D_LOSS_WS_DOUBLES doubles, need not be initialised */, float* loss_out /* [8] */,
+                   float* dL_dcolor, float* dL_dallmap,
                    void* stream);
 
 /*
