@@ -49,7 +49,7 @@ def lib():
     L.gs2d_binning_layout.argtypes = [i, C.POINTER(sz)]
     L.gs2d_image_layout.argtypes = [i, i, C.POINTER(sz)]
     L.gs2d_slam_loss.restype = i
-    L.gs2d_slam_loss.argtypes = [i, i, i, vp, vp, vp, vp, f, f, f, f, f, i, i, f, f, f, vp, vp, vp, vp, vp]
+    L.gs2d_slam_loss.argtypes = [i, i, i, vp, vp, vp, vp, f, f, f, f, f, i, i, f, f, f, vp, vp, vp, vp, vp, vp]
     L.gs2d_adam_step.restype = i
     L.gs2d_adam_step.argtypes = [i, vp, vp, f, f, f, i, C.c_ulonglong, vp, vp, vp, vp, vp]
     L.gs2d_stage_timing_enable.argtypes = [i]

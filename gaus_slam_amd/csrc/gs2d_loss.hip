@@ -107,7 +107,8 @@ loss_reduce_kernel(LossCfg L, int HWi, const float* __restrict__ color, const fl
 __global__ void __launch_bounds__(256)
 loss_grad_kernel(LossCfg L, int HWi, int nparts, const float* __restrict__ color, const float* __restrict__ allmap,
                  const float* __restrict__ gt_color, const float* __restrict__ gt_depth, const double* __restrict__ partial,
-                 float* __restrict__ loss_out, float* __restrict__ dL_dcolor, float* __restrict__ dL_dallmap)
+                 float* __restrict__ loss_out, float* __restrict__ dL_dcolor, float* __restrict__ dL_dallmap,
+                 const float* __restrict__ upstream)
 {
     __shared__ double red[4];
     const size_t HW = (size_t)HWi;
@@ -121,7 +122,8 @@ loss_grad_kernel(LossCfg L, int HWi, int nparts, const float* __restrict__ color
         gd_scale = (float)(L.w_depth / nd);
         gdist_scale = (float)(L.w_dist / nc);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (upstream) { const float u = upstream[0]; gc_scale *= u; gd_scale *= u; gdist_scale *= u; }  // dL/dloss from autograd
+    if (loss_out && blockIdx.x == 0 && threadIdx.x == 0) {
         double loss;
         if (L.mode == 0) loss = L.w_color * acc[0] + L.w_depth * acc[1];
         else loss = L.w_color * (acc[0] / (3.0 * nc)) + L.w_depth * (acc[1] / nd) + L.w_dist * (acc[2] / nc);
@@ -129,6 +131,7 @@ loss_grad_kernel(LossCfg L, int HWi, int nparts, const float* __restrict__ color
         loss_out[1] = (float)acc[0]; loss_out[2] = (float)acc[1]; loss_out[3] = (float)acc[2];
         loss_out[4] = (float)nc; loss_out[5] = (float)nd;
     }
+    if (!dL_dcolor) return;  // loss-only call
     for (size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x; pix < HW; pix += (size_t)gridDim.x * 256) {
         const PixelTerms t = pixel_terms(L, HW, pix, color, allmap, gt_depth);
         const bool dmask = L.mode == 0 ? t.color_mask : t.depth_mask;
@@ -157,10 +160,12 @@ extern "C" int gs2d_slam_loss(int mode, int width, int height, const float* colo
                               const float* gt_color_hwc, const float* gt_depth, float w_color, float w_depth, float w_dist,
                               float silmask_th, float edge_thres, int use_edge_growth, int use_weight_norm, float eps,
                               float depth_near, float depth_far, double* workspace /* >= GS2D_LOSS_WS_DOUBLES doubles */, float* loss_out /* [8] */,
-                              float* dL_dcolor, float* dL_dallmap, void* stream)
+                              float* dL_dcolor, float* dL_dallmap, const float* upstream, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
     if (width <= 0 || height <= 0 || (mode != 0 && mode != 1)) return -1;
+    if ((dL_dcolor == nullptr) != (dL_dallmap == nullptr)) return -1;
+    if (!loss_out && !dL_dcolor) return -1;
     LossCfg L;
     L.mode = mode; L.use_weight_norm = use_weight_norm; L.use_edge_growth = use_edge_growth;
     L.w_color = w_color; L.w_depth = w_depth; L.w_dist = w_dist; L.silmask_th = silmask_th; L.edge_thres = edge_thres;
@@ -170,8 +175,11 @@ extern "C" int gs2d_slam_loss(int mode, int width, int height, const float* colo
     const int rgrid = blocks < LOSS_MAX_BLOCKS ? blocks : LOSS_MAX_BLOCKS;  // one partial per reduce block, <= 256
     const int ggrid = blocks < 2048 ? blocks : 2048;
     static_assert(LOSS_MAX_BLOCKS * 5 <= GS2D_LOSS_WS_DOUBLES, "workspace too small");
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(rgrid), dim3(256), 0, s, L, HW, color, allmap, gt_color_hwc, gt_depth, workspace);
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(ggrid), dim3(256), 0, s, L, HW, rgrid, color, allmap, gt_color_hwc, gt_depth,
-                       workspace, loss_out, dL_dcolor, dL_dallmap);
+    // loss_out != NULL: run the reduction (pass 1).  dL_d* != NULL: write gradients (pass 2, scaled by *upstream if
+    // given).  A gradients-only call (loss_out == NULL) reuses the partial sums a previous loss call left in `workspace`.
+    if (loss_out)
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(rgrid), dim3(256), 0, s, L, HW, color, allmap, gt_color_hwc, gt_depth, workspace);
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(dL_dcolor ? ggrid : 1), dim3(256), 0, s, L, HW, rgrid, color, allmap, gt_color_hwc,
+                       gt_depth, workspace, loss_out, dL_dcolor, dL_dallmap, upstream);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

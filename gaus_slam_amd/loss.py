@@ -12,7 +12,24 @@ import torch
 from . import _lib
 
 
+def _call(cfg, W, H, color_, allmap_, gtc, gtd, ws, out, g_color, g_allmap, upstream, dev):
+    p = lambda t: None if t is None else t.data_ptr()
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gs2d_slam_loss(
+            int(cfg["mode"]), W, H, color_.data_ptr(), allmap_.data_ptr(), gtc.data_ptr(), gtd.data_ptr(),
+            float(cfg["w_color"]), float(cfg["w_depth"]), float(cfg.get("w_dist", 0.0)), float(cfg.get("silmask_th", 0.9)),
+            float(cfg.get("edge_thres", 0.4)), int(bool(cfg.get("use_edge_growth", False))),
+            int(bool(cfg.get("use_weight_norm", True))), float(cfg.get("eps", 1e-6)), float(cfg.get("depth_near", 1e-2)),
+            float(cfg.get("depth_far", 1e2)), ws.data_ptr(), p(out), p(g_color), p(g_allmap), p(upstream),
+            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc < 0:
+        raise RuntimeError("gs2d_slam_loss failed")
+
+
 class _SlamLoss(torch.autograd.Function):
+    """forward = the reduction pass only (loss value); backward = the gradient pass, scaled in-kernel by dL/dloss.  The
+    partial sums of the forward stay in `ws` for the backward."""
+
     @staticmethod
     def forward(ctx, color, allmap, gt_color, gt_depth, cfg):
         if not color.is_cuda:
@@ -24,25 +41,21 @@ class _SlamLoss(torch.autograd.Function):
         gtd = gt_depth.detach().float().contiguous().reshape(H, W)
         ws = torch.empty(1280, dtype=torch.float64, device=dev)  # GS2D_LOSS_WS_DOUBLES
         out = torch.empty(8, dtype=torch.float32, device=dev)
-        g_color, g_allmap = torch.empty_like(color_), torch.empty_like(allmap_)
-        with torch.cuda.device(dev):
-            rc = _lib.lib().gs2d_slam_loss(
-                int(cfg["mode"]), W, H, color_.data_ptr(), allmap_.data_ptr(), gtc.data_ptr(), gtd.data_ptr(),
-                float(cfg["w_color"]), float(cfg["w_depth"]), float(cfg.get("w_dist", 0.0)), float(cfg.get("silmask_th", 0.9)),
-                float(cfg.get("edge_thres", 0.4)), int(bool(cfg.get("use_edge_growth", False))),
-                int(bool(cfg.get("use_weight_norm", True))), float(cfg.get("eps", 1e-6)), float(cfg.get("depth_near", 1e-2)),
-                float(cfg.get("depth_far", 1e2)), ws.data_ptr(), out.data_ptr(), g_color.data_ptr(), g_allmap.data_ptr(),
-                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
-        if rc < 0:
-            raise RuntimeError("gs2d_slam_loss failed")
-        ctx.save_for_backward(g_color, g_allmap)
+        _call(cfg, W, H, color_, allmap_, gtc, gtd, ws, out, None, None, None, dev)
+        ctx.save_for_backward(color_, allmap_, gtc, gtd, ws)
+        ctx.cfg = cfg
         ctx.terms = out
         return out[0]
 
     @staticmethod
     def backward(ctx, grad_loss):
-        g_color, g_allmap = ctx.saved_tensors
-        return g_color * grad_loss, g_allmap * grad_loss, None, None, None
+        color_, allmap_, gtc, gtd, ws = ctx.saved_tensors
+        dev = color_.device
+        H, W = color_.shape[1], color_.shape[2]
+        g_color, g_allmap = torch.empty_like(color_), torch.empty_like(allmap_)
+        up = grad_loss.detach().to(dtype=torch.float32).contiguous()
+        _call(ctx.cfg, W, H, color_, allmap_, gtc, gtd, ws, None, g_color, g_allmap, up, dev)
+        return g_color, g_allmap, None, None, None
 
 
 def tracking_loss(color, allmap, gt_color, gt_depth, w_color, w_depth, silmask_th=0.9, use_weight_norm=True, eps=1e-6,

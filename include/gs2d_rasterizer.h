@@ -143,6 +143,8 @@ int sknn_dist2(int N, const float* points, float* out,
  * mode 0 = tracking (masked sums), 1 = mapping (masked means + dist term).  color [3,H,W], allmap [7,H,W] are the raw
  * rasterizer outputs, gt_color_hwc [H,W,3], gt_depth [H,W].  Writes loss_out[0] = loss (loss_out[1..5] = colour sum,
  * depth sum, dist sum, #colour-mask, #depth-mask) and the gradients of the loss w.r.t. color / allmap.
+ * Two-phase use (what the autograd node does): call with dL_dcolor = dL_dallmap = NULL for the loss alone, later with
+ * loss_out = NULL (same inputs, same workspace) for the gradients, scaled by the device scalar *upstream.
  * Default-configuration losses only (no normal loss, no outlier rejection, no exposure).
  */
 #define GS2D_LOSS_WS_DOUBLES 1280
@@ -150,7 +152,7 @@ int gs2d_slam_loss(int mode, int width, int height, const float* color, const fl
                    const float* gt_depth, float w_color, float w_depth, float w_dist, float silmask_th, float edge_thres,
                    int use_edge_growth, int use_weight_norm, float eps, float depth_near, float depth_far,
                    double* workspace /* >= GS2D_LOSS_WS_DOUBLES doubles, need not be initialised */, float* loss_out /* [8] */,
-                   float* dL_dcolor, float* dL_dallmap,
+                   float* dL_dcolor, float* dL_dallmap, const float* upstream /* device scalar dL/dloss or NULL (= 1) */,
                    void* stream);
 
 /*

@@ -70,7 +70,9 @@ def track_fused():
     opt_fus.step()
 
 
-print(f"tracking iteration @ {W}x{H}, {P} Gaussians:  reference formulation {timeit(track_ref):.3f} ms   fused {timeit(track_fused):.3f} ms")
+FUSED_ONLY = "--fused-only" in sys.argv  # for profiling the fused path alone
+t_ref = float("nan") if FUSED_ONLY else timeit(track_ref)
+print(f"tracking iteration @ {W}x{H}, {P} Gaussians:  reference formulation {t_ref:.3f} ms   fused {timeit(track_fused):.3f} ms")
 
 # ------------------------------------------------------------------ mapping
 sc = make_scene(P, W, H, seed=0, regime="mapping")
@@ -103,4 +105,5 @@ def map_fused():
     fopt.step(ba.bucket.flat)
 
 
-print(f"mapping  iteration @ {W}x{H}, {P} Gaussians:  reference formulation {timeit(map_ref):.3f} ms   fused {timeit(map_fused):.3f} ms")
+m_ref = float("nan") if FUSED_ONLY else timeit(map_ref)
+print(f"mapping  iteration @ {W}x{H}, {P} Gaussians:  reference formulation {m_ref:.3f} ms   fused {timeit(map_fused):.3f} ms")
