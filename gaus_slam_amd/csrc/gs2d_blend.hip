@@ -571,6 +571,7 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
 struct BwdBatch {
     float4 q[4][64];
     float acc[64 * GS2D_ACC];
+    uint32_t pn[64];  // list position << 4 | cull bits of the staged splat
 };
 
 template <bool USE_SA>
@@ -646,44 +647,74 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     // normal channels (SLAM's losses never touch them unless use_normal_loss), everything that only feeds
     // dL_dnormal / the normal term of dL_dalpha is exactly zero and is skipped.  Results are unchanged.
     const bool any_dn = __ballot(dn0 != 0.f || dn1 != 0.f || dn2 != 0.f) != 0;
-    const int nbatches = (int)((max_last + 63) / 64);
+    // Batches are COMPACTED: the list is read in 64-instance chunks (back to front), but only the splats whose cull bits
+    // (stored by the forward) touch this quadrant are staged, and chunks keep being added until all 64 LDS slots are in
+    // use (a chunk that does not fit is split: its shallower part is carried into the next batch).  Compared with
+    // "one chunk = one batch" the four row queues are ~3.5x longer per batch, so waiting for the longest queue costs
+    // relatively less, untouched records are never loaded, and there are fewer batch prologues and flushes.
+    // Slots are handed out from 63 downwards, deepest splat first, so a queue popped from its highest bit walks the
+    // splats back to front exactly as before.
+    int chunk = (int)((max_last + 63) / 64) - 1;  // next chunk to read
+    int carry_chunk = -1;                           // chunk whose shallower part is still waiting
+    uint32_t carry_tm = 0u;
     GS2D_PROF_BEGIN();
-    for (int b = nbatches - 1; b >= 0; b--) {
-        const uint32_t b0 = (uint32_t)b * 64;
-        const int n = (int)min(64u, max_last - b0);
-        uint32_t tm = 0u;
+    for (;;) {
+        int fill = 0;
         wave_lds_sync();  // previous batch fully consumed before it is overwritten
-        if (lane < n) {
-            const uint32_t my_id = point_list[range.x + b0 + lane];
-            const float4* rp = rec + (size_t)my_id * GS2D_REC_F4;
-            const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-            const float red = rp[3].w;
-            const float4 r4 = rp[4];
-            // queues come from the cull bits the forward stored for this (instance, quadrant): no second cull test
-            tm = hits[(size_t)(range.x + b0 + lane) * 4 + wave];
-            wb.q[0][lane] = r0; wb.q[1][lane] = r1; wb.q[2][lane] = r2;
-            wb.q[3][lane] = make_float4(red, r4.x, r4.y, __uint_as_float(my_id));  // colour + the Gaussian id
+        for (;;) {
+            uint32_t tm;
+            int cb;
+            if (carry_chunk >= 0) { tm = carry_tm; cb = carry_chunk; carry_chunk = -1; }
+            else {
+                if (chunk < 0) break;
+                cb = chunk--;
+                const int n = (int)min(64u, max_last - (uint32_t)cb * 64u);
+                // queues come from the cull bits the forward stored for this (instance, quadrant): no second cull test
+                tm = lane < n ? hits[(size_t)(range.x + (uint32_t)cb * 64u + lane) * 4 + wave] : 0u;
+            }
+            const uint64_t tb = __ballot(tm != 0u);
+            const int c = __popcll(tb);
+            if (c == 0) continue;
+            // deepest touched lane -> highest free slot: touched lanes above me = c - 1 - (touched lanes below me)
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(tb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tb, 0u));
+            const int slot = 64 - fill - c + below;
+            const bool take = tm != 0u && slot >= 0;
+            if (take) {
+                const uint32_t pos = (uint32_t)cb * 64u + lane;
+                const uint32_t my_id = point_list[range.x + pos];
+                const float4* rp = rec + (size_t)my_id * GS2D_REC_F4;
+                const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+                const float red = rp[3].w;
+                const float4 r4 = rp[4];
+                wb.q[0][slot] = r0; wb.q[1][slot] = r1; wb.q[2][slot] = r2;
+                wb.q[3][slot] = make_float4(red, r4.x, r4.y, __uint_as_float(my_id));  // colour + the Gaussian id
+                wb.pn[slot] = (pos << 4) | tm;                                         // list position + cull bits
+            }
+            if (fill + c > 64) { carry_tm = take ? 0u : tm; carry_chunk = cb; fill = 64; break; }
+            fill += c;
+            if (fill == 64) break;
         }
+        if (fill == 0) break;  // list exhausted
         wave_lds_sync();
-        // four depth-ordered queues, one per 4x4 sub-block (= DPP row), walked back to front
-        uint64_t m0 = __ballot(tm & 1u), m1 = __ballot(tm & 2u), m2 = __ballot(tm & 4u), m3 = __ballot(tm & 8u);
-        if ((m0 | m1 | m2 | m3) == 0) continue;
-        uint64_t touched = m0 | m1 | m2 | m3;  // splats of this batch that may receive a gradient from this quadrant
+        // four depth-ordered queues (bit = slot), one per 4x4 sub-block (= DPP row), walked back to front
+        const uint32_t nib = lane >= 64 - fill ? wb.pn[lane] : 0u;
+        uint64_t m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u), m2 = __ballot(nib & 4u), m3 = __ballot(nib & 8u);
         int j;
         {
             const int j0 = pop_back(m0), j1 = pop_back(m1), j2 = pop_back(m2), j3 = pop_back(m3);
             j = row_select(row8, j0, j1, j2, j3);
         }
         float4 ga0 = wb.q[0][j & 63], ga1 = wb.q[1][j & 63], ga2 = wb.q[2][j & 63];
+        uint32_t gap = wb.pn[j & 63], gbp;
         float4 gb0, gb1, gb2;
-#define GS2D_BWD_STEP(G0, G1, G2, N0_, N1_, N2_)                                                                      \
+#define GS2D_BWD_STEP(G0, G1, G2, GP, N0_, N1_, N2_, NP_)                                                                    \
         {                                                                                                             \
             GS2D_PROF_TRIP();                                                                                         \
             const bool more = (m0 | m1 | m2 | m3) != 0;                                                               \
             const int jn = row_select(row8, pop_back(m0), pop_back(m1), pop_back(m2), pop_back(m3));                  \
-            N0_ = wb.q[0][jn & 63]; N1_ = wb.q[1][jn & 63]; N2_ = wb.q[2][jn & 63];                                   \
+            N0_ = wb.q[0][jn & 63]; N1_ = wb.q[1][jn & 63]; N2_ = wb.q[2][jn & 63]; NP_ = wb.pn[jn & 63];             \
             const float4 cc = wb.q[3][j & 63]; /* r, g, b, id */                                                      \
-            const uint32_t contributor = b0 + (uint32_t)j; /* 0-based, as in backward.cu:285 */                       \
+            const uint32_t contributor = GP >> 4; /* list position, 0-based, as in backward.cu:285 */                 \
             bool active = inside && j < 64 && contributor < last_contributor; /* j == 64: row queue exhausted */      \
             if (__ballot(active) != 0) {                                                                              \
                 /* Part A (all lanes): same geometry / alpha as the forward */                                        \
@@ -814,12 +845,13 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
             j = jn;                                                                                                   \
         }
         for (;;) {
-            GS2D_BWD_STEP(ga0, ga1, ga2, gb0, gb1, gb2)
-            GS2D_BWD_STEP(gb0, gb1, gb2, ga0, ga1, ga2)
+            GS2D_BWD_STEP(ga0, ga1, ga2, gap, gb0, gb1, gb2, gbp)
+            GS2D_BWD_STEP(gb0, gb1, gb2, gbp, ga0, ga1, ga2, gap)
         }
 #undef GS2D_BWD_STEP
         // flush: every touched splat of the batch goes to its global record once, four splats (one per row) per pass
         // two passes (eight splats) per iteration so the LDS round trips of one pass hide behind the other
+        uint64_t touched = fill == 64 ? ~0ull : (~0ull << (64 - fill));  // the staged slots
         const int flush_off = li < 3 ? li : (li < 12 ? li + 3 : 15);  // accumulator li -> offset in the gradient record
         const bool flush_lane = li < GS2D_ACC;
         while (GS2D_EXP_FLUSH(touched)) {

@@ -26,10 +26,10 @@ void trip_sim(int W, int H, const uint32_t* ranges, const uint32_t* point_list, 
               const float* normal_opacity, const uint32_t* n_contrib, double* out)
 {
     int gx = (W + 15) / 16, gy = (H + 15) / 16;
-    double acc[10] = {0}; double accx = 0;
+    double acc[10] = {0}; double accx = 0, accy = 0;
 #pragma omp parallel for schedule(dynamic, 4)
     for (int t = 0; t < gx * gy; t++) {
-        double loc[10] = {0}; double locx = 0;
+        double loc[10] = {0}; double locx = 0, locy = 0;
         int tx = t % gx, ty = t / gx;
         uint32_t s = ranges[2 * t], e = ranges[2 * t + 1];
         for (int q = 0; q < 4; q++) {
@@ -46,6 +46,7 @@ void trip_sim(int W, int H, const uint32_t* ranges, const uint32_t* point_list, 
             double tot4[4] = {0}, tot2[16] = {0};
             int c2_128[16] = {0};
             int cb4[4] = {0}, cb_fill = 0; double cb_trips = 0;
+            int fb4[4] = {0}, fb_fill = 0; double fb_trips = 0;
             for (uint32_t base = s; base < e && (base - s) < qlast; base += 64) {
                 int c4[4] = {0}, c2[16] = {0}, c8 = 0;
                 for (uint32_t j = base; j < e && j < base + 64; j++) {
@@ -60,6 +61,10 @@ void trip_sim(int W, int H, const uint32_t* ranges, const uint32_t* point_list, 
                     }
                     if (!m) continue;
                     c8++;
+                    { /* exact 64-slot batches */
+                        for (int r = 0; r < 4; r++) { uint64_t rm = 0; for (int yy = 0; yy < 4; yy++) rm |= 0xFull << (((r >> 1) * 4 + yy) * 8 + (r & 1) * 4); if (m & rm) fb4[r]++; }
+                        if (++fb_fill == 64) { int mm = 0; for (int r = 0; r < 4; r++) { if (fb4[r] > mm) mm = fb4[r]; fb4[r] = 0; } fb_trips += mm; fb_fill = 0; }
+                    }
                     loc[6] += __builtin_popcountll(m);
                     for (int r = 0; r < 4; r++) {
                         uint64_t rm = 0;
@@ -87,14 +92,15 @@ void trip_sim(int W, int H, const uint32_t* ranges, const uint32_t* point_list, 
             }
             { int mm = 0; for (int r = 0; r < 4; r++) if (cb4[r] > mm) mm = cb4[r]; cb_trips += mm; }
             loc[8] = loc[8] * 0 + loc[8]; loc[9] += 0; loc[5] += 0; loc[4] += 0; loc[3] += 0; loc[2] += 0; loc[1] += 0; loc[0] += 0; loc[7] += 0; loc[6] += 0;
-            locx += cb_trips;
+            { int mm = 0; for (int r = 0; r < 4; r++) if (fb4[r] > mm) mm = fb4[r]; fb_trips += mm; }
+            locx += cb_trips; locy += fb_trips;
             double d4 = 0, d2 = 0;
             for (int r = 0; r < 4; r++) if (tot4[r] > d4) d4 = tot4[r];
             for (int g = 0; g < 16; g++) if (tot2[g] > d2) d2 = tot2[g];
             loc[2] += d4; loc[3] += d2;
         }
 #pragma omp critical
-        { for (int i = 0; i < 10; i++) acc[i] += loc[i]; accx += locx; }
+        { for (int i = 0; i < 10; i++) acc[i] += loc[i]; accx += locx; accy += locy; }
     }
-    memcpy(out, acc, sizeof(acc)); out[10] = accx;
+    memcpy(out, acc, sizeof(acc)); out[10] = accx; out[11] = accy;
 }
