@@ -245,7 +245,7 @@ __device__ __forceinline__ int xcd_tile(int block, int ntiles)
 }
 
 template <bool USE_SA>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
 blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
                  float* __restrict__ out_others, float* __restrict__ pix_state, size_t plane, uint8_t* __restrict__ hits)
@@ -273,23 +273,55 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     bool done = !inside;
     GS2D_PROF_BEGIN();
 
-    for (uint32_t base = range.x; base < range.y; base += 64) {
+    // Batches are COMPACTED (see the backward for the rationale): the list is read in 64-instance chunks, every lane
+    // culls one splat, but only the splats that touch this quadrant are staged, and chunks keep being added until the 64
+    // LDS slots are full.  A chunk that does not fit is split: the lanes left over keep their cull bits (carry_tm) and
+    // are staged first in the next batch (their records are simply fetched again).
+    uint32_t next_chunk = range.x;  // absolute index of the next chunk to read
+    uint32_t carry_base = 0;
+    uint32_t carry_tm = 0u;
+    bool carry = false;
+    for (;;) {
         if (__ballot(!done) == 0) break;
-        const int n = min(64, (int)(range.y - base));
-        uint32_t tm = 0u;
+        int fill = 0;
         wave_lds_sync();  // previous batch fully consumed before it is overwritten
-        if (lane < n) {
-            const uint32_t id = point_list[base + lane];
-            const float4* rp = rec + (size_t)id * GS2D_REC_F4;
-            const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4];
-            tm = splat_touch_mask(r0, r1, r2, r4.z, (float)qx0, (float)qy0);
-            // one byte per (instance, quadrant): the backward rebuilds its row queues from these bits, no second cull test
-            hits[(size_t)(base + lane) * 4 + wave] = (uint8_t)tm;
-            wb.q[0][lane] = r0; wb.q[1][lane] = r1; wb.q[2][lane] = r2; wb.q[3][lane] = r3; wb.q[4][lane] = r4;
+        for (;;) {
+            uint32_t cbase, tm = 0u;
+            bool fresh;
+            if (carry) { cbase = carry_base; tm = carry_tm; carry = false; fresh = false; }
+            else {
+                if (next_chunk >= range.y) break;
+                cbase = next_chunk; next_chunk += 64; fresh = true;
+            }
+            const bool need = fresh ? (cbase + lane < range.y) : (tm != 0u);
+            float4 r0, r1, r2, r3, r4;
+            if (need) {
+                const uint32_t id = point_list[cbase + lane];
+                const float4* rp = rec + (size_t)id * GS2D_REC_F4;
+                r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4];
+                if (fresh) {
+                    tm = splat_touch_mask(r0, r1, r2, r4.z, (float)qx0, (float)qy0);
+                    // one byte per (instance, quadrant): the backward rebuilds its row queues from these bits
+                    hits[(size_t)(cbase + lane) * 4 + wave] = (uint8_t)tm;
+                }
+            }
+            const uint64_t tb = __ballot(tm != 0u);
+            const int c = __popcll(tb);
+            if (c == 0) continue;
+            const int slot = fill + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(tb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tb, 0u));
+            const bool take = tm != 0u && slot < 64;
+            if (take) {
+                r4.w = __uint_as_float(((cbase - range.x + lane) << 4) | tm);  // list position + cull bits ride in the free slot
+                wb.q[0][slot] = r0; wb.q[1][slot] = r1; wb.q[2][slot] = r2; wb.q[3][slot] = r3; wb.q[4][slot] = r4;
+            }
+            if (fill + c > 64) { carry_tm = take ? 0u : tm; carry_base = cbase; carry = true; fill = 64; break; }
+            fill += c;
+            if (fill == 64) break;
         }
+        if (fill == 0) break;  // list exhausted
         wave_lds_sync();
-        uint64_t m0 = __ballot(tm & 1u), m1 = __ballot(tm & 2u), m2 = __ballot(tm & 4u), m3 = __ballot(tm & 8u);
-        if ((m0 | m1 | m2 | m3) == 0) continue;
+        const uint32_t nib = lane < fill ? __float_as_uint(wb.q[4][lane].w) : 0u;
+        uint64_t m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u), m2 = __ballot(nib & 4u), m3 = __ballot(nib & 8u);
         // software pipeline: the records of the NEXT trip are fetched from LDS while the current ones are evaluated;
         // unrolled by two with the two register sets swapping roles (no copies).
         int j;
@@ -315,7 +347,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
             const bool stop = pass && test_T < 0.0001f;                                                              \
             done = done || stop;                                                                                     \
             if (pass && !stop) {                                                                                     \
-                const uint32_t contributor = (base - range.x) + (uint32_t)j + 1u;                                    \
+                const uint32_t contributor = (__float_as_uint(C4.w) >> 4) + 1u; /* list position + 1 */             \
                 const float w = alpha * T;                                                                           \
                 if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }                            \
                 if (USE_SA) { /* forward.cu:405-416 */                                                               \
