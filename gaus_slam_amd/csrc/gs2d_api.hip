@@ -305,6 +305,11 @@ int gs2d_backward_posed(int P, int D, int M, int R, const float* background, int
 {
     if ((pose_Rt == nullptr) != (pose_quat == nullptr)) return fail_msg("pose_Rt and pose_quat must be given together");
     if (pose_Rt != nullptr && dL_dpose == nullptr) return fail_msg("dL_dpose is required with a pose");
+    {   // pose-only call: all six per-Gaussian outputs NULL (needs a pose and no SH gradient), otherwise none of them
+        const int nulls = !dL_dmean2D + !dL_dopacity + !dL_dcolor + !dL_dmean3D + !dL_dscale + !dL_drot;
+        if (nulls != 0 && (nulls != 6 || pose_Rt == nullptr || shs != nullptr))
+            return fail_msg("per-Gaussian gradient outputs may only be omitted all together, with a pose and without SH");
+    }
     if (dL_dpose != nullptr)
         GS2D_CHECK(hipMemsetAsync(dL_dpose, 0, sizeof(float) * 12, (hipStream_t)stream), "memset dL_dpose");
     (void)colors_precomp; (void)transMat_precomp; (void)scale_modifier;
@@ -362,6 +367,13 @@ int gs2d_backward(int P, int D, int M, int R, const float* background, int width
                                geom_buffer, binning_buffer, img_buffer, dL_dpix, dL_depths, dL_dmean2D, dL_dnormal,
                                dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot, use_sa, debug,
                                nullptr, nullptr, nullptr, stream);
+}
+
+int gs2d_pose_quat(const float* pose_Rt, float* quat_out, void* stream)
+{
+    if (!pose_Rt || !quat_out) return fail_msg("null pointer");
+    gs2d::launch_pose_quat(pose_Rt, quat_out, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail_msg("pose_quat launch failed");
 }
 
 int gs2d_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,

@@ -122,6 +122,7 @@ void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const floa
                            float* dL_dmean3D, float* dL_dscale, float* dL_drot, const float* pose_Rt, const float* pose_q,
                            float* dL_dpose, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
+void launch_pose_quat(const float* pose_Rt, float* q_out, hipStream_t s);
 // inclusive scan of n u32; tmp must hold ceil(n/1024)+64 u32. If total_out != nullptr the grand total is stored there.
 // total_host (optional): pinned host word that receives the total with a system-scope store as soon as it is known.
 void launch_inclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* tmp, uint32_t* total_out, hipStream_t s,

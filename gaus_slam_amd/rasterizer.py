@@ -117,7 +117,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, use_sa,
-                                 debug, pose_Rt=None, pose_quat=None, grad_sink=None, lean=False):
+                                 debug, pose_Rt=None, pose_quat=None, grad_sink=None, lean=False, pose_only_out=None):
     """_C.rasterize_gaussians_backward (rasterize_points.cu:140-239): returns
     (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dtransMat[P,9], dL_dsh[P,M,3],
      dL_dscales[P,2], dL_drotations[P,4]).
@@ -125,7 +125,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     the gradient's shape; the kernels then write those gradients there (e.g. straight into the all-reduce bucket) instead
     of into fresh tensors.
     lean (used by the autograd node): skip the outputs nobody can observe there -- the internal dL_dnormal and, when no
-    cov3D_precomp was given, dL_dtransMat (returned as None): 48 B per Gaussian less to write."""
+    cov3D_precomp was given, dL_dtransMat (returned as None): 48 B per Gaussian less to write.
+    pose_only_out (tracking): a zeroed float32 tensor whose first 12 elements receive dL/d[R|t]; no per-Gaussian gradient
+    is computed or allocated and only that tensor is returned."""
     for name, t in (("background", background), ("means3D", means3D), ("radii", radii), ("colors", colors),
                     ("scales", scales), ("rotations", rotations), ("transMat_precomp", transMat_precomp),
                     ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("sh", sh), ("campos", campos),
@@ -136,6 +138,23 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.size(0) != 0 else 0
+    if pose_only_out is not None:
+        if pose_Rt is None or M != 0:
+            raise RuntimeError("pose_only_out needs a pose and colors_precomp")
+        if P != 0:
+            keep = [_f32c(t) for t in (background, means3D, colors, scales, rotations, viewmatrix, projmatrix, campos,
+                                       dL_dout_color, dL_dout_others, pose_Rt, pose_quat)]
+            bg_, m3_, col_, sc_, rot_, vm_, pm_, cp_, dc_, do_, prt_, pq_ = keep
+            with torch.cuda.device(dev):
+                rc = L.gs2d_backward_posed(
+                    P, int(degree), 0, int(R), _ptr(bg_), W, H, _ptr(m3_), None, _ptr(col_), _ptr(sc_), float(scale_modifier),
+                    _ptr(rot_), None, _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy),
+                    radii.contiguous().data_ptr(), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), dc_.data_ptr(),
+                    do_.data_ptr(), None, None, None, None, None, None, None, None, None, int(bool(use_sa)), int(bool(debug)),
+                    _ptr(prt_), _ptr(pq_), pose_only_out.data_ptr(), _stream_ptr(dev))
+            if rc < 0:
+                raise RuntimeError(_lib.last_error())
+        return pose_only_out
     # the backward kernels write every element (zeros for culled Gaussians): no torch.zeros fills needed
     z = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dnormal = z(P, 3), z(P, 3), z(P, NUM_CHANNELS), z(P, 3)

@@ -27,8 +27,22 @@ def matrix_to_quaternion(R: torch.Tensor) -> torch.Tensor:
         torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[3] ** 2]),
     ])
     cand = cand / (2.0 * q_abs[:, None].clamp(min=0.1))
-    q = cand[int(torch.argmax(q_abs))]
+    q = cand[torch.argmax(q_abs)]  # tensor index: no host synchronisation
     return torch.where(q[0:1] < 0, -q, q)
+
+
+def pose_quaternion(pose_Rt: torch.Tensor) -> torch.Tensor:
+    """matrix_to_quaternion of the rotation block of a contiguous float32 [3,4] device tensor, computed by one tiny kernel
+    (gs2d_pose_quat): no host sync and a single launch instead of ~20 PyTorch ops per tracking iteration."""
+    import ctypes as C
+    from . import _lib
+    q = torch.empty(4, dtype=torch.float32, device=pose_Rt.device)
+    with torch.cuda.device(pose_Rt.device):
+        rc = _lib.lib().gs2d_pose_quat(pose_Rt.data_ptr(), q.data_ptr(),
+                                       C.c_void_p(torch.cuda.current_stream(pose_Rt.device).cuda_stream))
+    if rc < 0:
+        raise RuntimeError(_lib.last_error())
+    return q
 
 
 class _RasterizeTracking(torch.autograd.Function):
@@ -36,7 +50,7 @@ class _RasterizeTracking(torch.autograd.Function):
     def forward(ctx, w2c, means3D, colors_precomp, opacities, scales, rotations, raster_settings):
         rs = raster_settings
         pose_Rt = w2c[:3, :4].detach().float().contiguous()
-        pose_q = matrix_to_quaternion(pose_Rt[:, :3]).contiguous()
+        pose_q = pose_quaternion(pose_Rt)
         e = torch.empty(0, dtype=torch.float32, device=means3D.device)
         num_rendered, color, allmap, radii, geom, binning, img = _r.rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, e, rs.viewmatrix,
@@ -53,6 +67,15 @@ class _RasterizeTracking(torch.autograd.Function):
         rs = ctx.rs
         colors_precomp, means3D, scales, rotations, radii, geom, binning, img, pose_Rt, pose_q = ctx.saved_tensors
         e = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        if not any(ctx.needs_input_grad[1:6]):
+            # the reference's tracking renderer detaches every Gaussian parameter (render/__init__.py:31-36): only the
+            # pose gradient is wanted; it is accumulated straight into the first three rows of the [4,4] result
+            g_w2c = torch.zeros((4, 4), dtype=torch.float32, device=means3D.device)
+            _r.rasterize_gaussians_backward(
+                rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix,
+                rs.tanfovx, rs.tanfovy, grad_color, grad_allmap, e, rs.sh_degree, rs.campos, geom, ctx.num_rendered, binning,
+                img, rs.use_sa, rs.debug, pose_Rt=pose_Rt, pose_quat=pose_q, pose_only_out=g_w2c)
+            return g_w2c, None, None, None, None, None, None
         (g_means2D, g_colors, g_opac, g_means3D, g_T, g_sh, g_scales, g_rot, g_pose) = _r.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix,
             rs.tanfovx, rs.tanfovy, grad_color, grad_allmap, e, rs.sh_degree, rs.campos, geom, ctx.num_rendered, binning,

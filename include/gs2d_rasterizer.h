@@ -110,7 +110,13 @@ int gs2d_backward(
  * with dL_dmean3D = R^T g_i and dL_drot mapped back to the untransformed quaternions.
  * pose_Rt: 12 floats row-major [R | t] (device); pose_quat: q_cam (w,x,y,z) (device).  Both NULL = plain call.
  * Typical use: identity viewmatrix / projection of the intrinsics only, as the reference's tracking renderer does.
+ * Pose-only backward: with a pose (and no SH), dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dscale and dL_drot may
+ * ALL be NULL -- tracking detaches every Gaussian parameter (render/__init__.py:31-36), only dL_dpose is produced then.
  */
+/* pose_quat for the calls below, computed on the device from pose_Rt's rotation block (pytorch3d's
+ * matrix_to_quaternion, real part first, w >= 0): quat_out = 4 floats (device).  No host synchronisation. */
+int gs2d_pose_quat(const float* pose_Rt, float* quat_out, void* stream);
+
 int gs2d_forward_posed(
     gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_alloc_fn binning_alloc, void* binning_user,
     gs2d_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,

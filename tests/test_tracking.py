@@ -137,3 +137,22 @@ def test_render_tracking_matches_unfused_reference_formulation():
     assert float((diff > 1e-4).float().mean()) < 5e-3
     assert util.grad_err(wf.grad.cpu().numpy()[:3], wu.grad.cpu().numpy()[:3]) < 2e-3
     assert float(wf.grad[3].abs().max()) == 0
+
+
+@pytest.mark.gpu
+def test_device_pose_quaternion_matches_torch_restatement():
+    """gs2d_pose_quat (one-thread kernel) against the PyTorch restatement of pytorch3d's matrix_to_quaternion, over
+    rotations that exercise all four candidate branches."""
+    from gaus_slam_amd import tracking
+    from gaus_slam_amd.scene_synth import random_w2c
+    rng = np.random.default_rng(7)
+    dev = torch.device("cuda")
+    mats = [random_w2c(rng, 180.0, 1.0) for _ in range(200)]
+    for ax in range(3):  # exact half turns: the w candidate is the worst one
+        R = -torch.eye(4); R[ax, ax] = 1.0; R[3, 3] = 1.0
+        mats.append(R)
+    for w in mats:
+        Rt = w[:3, :4].float().contiguous().to(dev)
+        got = tracking.pose_quaternion(Rt).cpu()
+        want = tracking.matrix_to_quaternion(w[:3, :3].float())
+        assert torch.allclose(got, want, atol=1e-6, rtol=0), (got, want)
