@@ -58,11 +58,16 @@ class KeyframeShardedBA:
     render_loss_fn(params, keyframe) -> scalar loss OR (outputs, upstream_grads) pair for torch.autograd.backward.
     """
 
-    def __init__(self, params, render_loss_fn, group=None, average=False, direct_grads=False):
+    def __init__(self, params, render_loss_fn, group=None, average=False, direct_grads=False, streams=2):
         """direct_grads: let the rasterizer's backward write the parameter gradients straight into the bucket (no pack
         copies).  Safe in every case -- a gradient that did not land in the bucket (the op was not fed the leaf itself,
         e.g. activations in between) is packed by copy as before."""
         self.direct_grads = direct_grads
+        # A rank that holds several keyframes of the batch renders them on `streams` HIP streams (forwards first, then
+        # backwards): at 640x480 one frame has 4800 quadrant-waves for 1024 SIMDs, so the kernels of a second frame
+        # fill the idle tails and the latency-bound binning stages of the first (measured: 1.34 vs 1.52 ms per pair).
+        self.n_streams = max(1, int(streams))
+        self._streams = None
         self.params = params
         self.fn = render_loss_fn
         self.group = group
@@ -94,6 +99,40 @@ class KeyframeShardedBA:
                 res.backward()
         return {k: p.grad for k, p in self.params.items()}
 
+    def _multi_stream_grads(self, mine):
+        """Per-keyframe gradient dicts, keyframes spread over the side streams; joined to the current stream on return."""
+        dev = self.params["means3D"].device
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)]
+        cur = torch.cuda.current_stream(dev)
+        names = list(self.params)
+        leaves = [self.params[n] for n in names]
+        pending = []
+        for i, kf in enumerate(mine):
+            st = self._streams[i % self.n_streams]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                pending.append(self.fn(self.params, kf))
+        out = []
+        for i, res in enumerate(pending):
+            st = self._streams[i % self.n_streams]
+            sink = contextlib.nullcontext()
+            if i == 0 and self.direct_grads:  # the first keyframe's gradients land in the bucket itself
+                from . import rasterizer
+                sink = rasterizer.grad_sink(self.bucket.views)
+            with torch.cuda.stream(st), sink:
+                if isinstance(res, tuple):
+                    gs = torch.autograd.grad(list(res[0]), leaves, list(res[1]), allow_unused=True)
+                else:
+                    gs = torch.autograd.grad(res, leaves, allow_unused=True)
+            for g in gs:
+                if g is not None:
+                    g.record_stream(cur)  # consumed on the current stream below
+            out.append({n: g for n, g in zip(names, gs)})
+        for st in self._streams:
+            cur.wait_stream(st)
+        return out
+
     def step(self, keyframes):
         """One BA step over a batch of keyframes (len == world_size in the bench; ragged batches allowed: ranks
         without a keyframe contribute zeros).  Returns the reduced bucket views (name -> [P,k])."""
@@ -105,6 +144,13 @@ class KeyframeShardedBA:
                                for name, v in self.bucket.views.items())
         if not mine:
             self.bucket.flat.zero_()
+        elif len(mine) > 1 and self.n_streams > 1 and self.params["means3D"].is_cuda:
+            per_kf = self._multi_stream_grads(mine)
+            self.bucket.pack(per_kf[0])
+            for g in per_kf[1:]:
+                for name, v in self.bucket.views.items():
+                    if g.get(name) is not None:
+                        v.add_(g[name].reshape(v.shape))
         else:
             acc = None
             for kf in mine:

@@ -365,3 +365,35 @@ def test_more_than_4096_tiles_takes_the_radix_pass_path(oracle):
     go = oracle.backward(o, dc, da)
     for k in ("dL_dmeans3D", "dL_dopacity", "dL_dcolors", "dL_dscales", "dL_drotations"):
         assert util.grad_err(gh[k], go[k].reshape(gh[k].shape)) <= GRAD_TOL, k
+
+
+@pytest.mark.filterwarnings("ignore:The AccumulateGrad node's stream")
+def test_two_keyframes_per_rank_on_two_streams_match_sequential(oracle):
+    """A rank holding two keyframes renders them on two HIP streams (ba_shard.KeyframeShardedBA, streams=2); the summed
+    gradients must equal the sequential single-stream result (float atomics reorder only)."""
+    from gaus_slam_amd import ba_shard, render as gsr
+    from gaus_slam_amd.scene_synth import random_w2c, setup_camera
+    W, H, P = 160, 120, 4000
+    sc = util.make_scene(P, W, H, seed=31, regime="mapping")
+    dev = torch.device("cuda")
+    cams = [sc["cam"], setup_camera(W, H, sc["cam"].K, random_w2c(np.random.default_rng(3), 3.0, 0.1) @ sc["cam"].w2c)]
+    settings = [gsr.settings_from_camera(c, dev, use_sa=True) for c in cams]
+    dc, da = [t.to(dev) * W * H for t in util.make_upstream_grads(W, H, channels=(0, 1, 6))]
+    names = ("means3D", "opacities", "scales", "rotations", "colors")
+
+    def fn(p, kf):
+        m2 = torch.zeros_like(p["means3D"], requires_grad=True)
+        pkg = gsr.render(settings[kf], p["means3D"], m2, p["opacities"], colors_precomp=p["colors"], scales=p["scales"],
+                         rotations=p["rotations"])
+        return (pkg["render_color"], pkg["allmap"]), (dc, da)
+
+    res = []
+    for streams in (1, 2):
+        params = {k: sc[k].to(dev).clone().requires_grad_(True) for k in names}
+        ba = ba_shard.KeyframeShardedBA(params, fn, streams=streams)
+        g = ba.step([0, 1])
+        torch.cuda.synchronize()
+        res.append({k: v.clone() for k, v in g.items()})
+    for k in names:
+        assert util.grad_err(res[1][k].cpu().numpy(), res[0][k].cpu().numpy()) < 1e-5, k
+        assert float(res[0][k].abs().max()) > 0
