@@ -159,6 +159,9 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef GS2D_WAVES_PER_EU
+#define GS2D_WAVES_PER_EU 5  // 96 VGPRs: all 1200 tiles of a 640x480 frame resident at once (5 workgroups per CU)
+#endif
 // Dev-only experiment hooks (scripts/dev/variants.sh builds variants with -DGS2D_EXPERIMENT=n; results are WRONG by
 // design, they only price one ingredient of blend_bwd via scripts/dev/stage_ms.py).  All pass-through in the product
 // build.  1: no global atomics in the flush   2: no butterfly   4: no flush loop   5: plain LDS store instead of ds_add_f32
@@ -245,7 +248,7 @@ __device__ __forceinline__ int xcd_tile(int block, int ntiles)
 }
 
 template <bool USE_SA>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS2D_WAVES_PER_EU, GS2D_WAVES_PER_EU)))
 blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
                  float* __restrict__ out_others, float* __restrict__ pix_state, size_t plane, uint8_t* __restrict__ hits)
@@ -607,7 +610,7 @@ struct BwdBatch {
 };
 
 template <bool USE_SA>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS2D_WAVES_PER_EU, GS2D_WAVES_PER_EU)))
 blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ pix_state,
                  size_t plane, const uint8_t* __restrict__ hits, const float* __restrict__ dL_dpix,
