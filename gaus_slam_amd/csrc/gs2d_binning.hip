@@ -511,11 +511,11 @@ void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* key
                             uint32_t* vals_alt, int packed, int write_keys, hipStream_t s)
 {
     if (R <= 0 || tiles <= 0) return;
-    // LDS capacity per tile: 1536, 2048 or 4096 elements (16 B each, <= 64 KB dynamic LDS), at least ~1.3x the mean
-    // list length.  Smaller capacity = more workgroups per CU (1536 -> 5 per CU, i.e. all 1200 tiles of a 640x480
-    // frame resident at once); the few tiles above the capacity take the global-memory variant.
-    const int avg = R / tiles;
-    const int cap = avg > 1300 ? 4096 : (avg > 1180 ? 2048 : 1536);
+    // LDS capacity per tile: the smallest of 1536 / 2048 / 3072 / 4096 elements (16 B each, <= 64 KB dynamic LDS) that
+    // is at least 1.3x the mean list length.  Smaller capacity = more workgroups per CU (1536 -> 5 per CU, i.e. all
+    // 1200 tiles of a 640x480 frame resident at once); the few tiles above the capacity take the global-memory variant.
+    const int want = (int)(((long long)R * 13) / ((long long)tiles * 10));
+    const int cap = want <= 1536 ? 1536 : (want <= 2048 ? 2048 : (want <= 3072 ? 3072 : 4096));
     hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(tiles), dim3(256), (size_t)cap * 16, s, ranges, keys, vals, keys_alt,
                        vals_alt, cap, packed, write_keys);
 }
