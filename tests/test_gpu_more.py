@@ -152,6 +152,16 @@ def test_full_bench_size_500k(oracle, regime):
     gh = util.hip_backward(h, dc, da)
     for k in ["dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dtransMat"]:
         assert util.grad_err(gh[k], go[k].reshape(gh[k].shape)) <= GRAD_TOL, k
+    # size-independent property: the backward is LINEAR in the upstream gradients (every term of backward.cu:143-664
+    # is), including on the knife-edge pixels and all ten channels -- checked at the full size without the oracle
+    u1 = util.make_upstream_grads(W, H, seed=11, channels=(0, 1, 2, 3, 4, 5, 6))
+    u2 = util.make_upstream_grads(W, H, seed=12, channels=(0, 1, 2, 3, 4, 5, 6))
+    c1, a1 = (u1[0] * W * H).numpy(), (u1[1] * W * H).numpy()
+    c2, a2 = (u2[0] * W * H).numpy(), (u2[1] * W * H).numpy()
+    g1, g2 = util.hip_backward(h, c1, a1), util.hip_backward(h, c2, a2)
+    g12 = util.hip_backward(h, 0.75 * c1 - 1.5 * c2, 0.75 * a1 - 1.5 * a2)
+    for k in ["dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"]:
+        assert util.grad_err(g12[k], 0.75 * g1[k] - 1.5 * g2[k]) <= GRAD_TOL, k
     oracle.set_threads(1)
 
 
