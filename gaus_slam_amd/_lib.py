@@ -24,6 +24,9 @@ def lib():
         raise RuntimeError(
             f"gaus_slam_amd: HIP library {path} is missing. Build it with `python -m gaus_slam_amd.build` "
             "(needs hipcc); this package has no CPU fallback.")
+    # torch first: its wheel bundles its own HIP runtime, and a process must end up with ONE libamdhip64.  Loading this
+    # library before torch pulls in /opt/rocm's copy as a second runtime, which then reports "no ROCm-capable device".
+    import torch  # noqa: F401
     L = C.CDLL(path)
     vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     L.gs2d_forward.restype = i
