@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _hip_library():
+    """(Re)build the gfx950 library when it is missing or older than its sources: hipcc cross-compiles without a GPU, so
+    this works in the CPU-only container as well as on the GPU box.  Without hipcc the stale/missing library is left
+    alone and the tests that need it fail loudly."""
+    from gaus_slam_amd import build as hip_build
+    try:
+        hip_build.build()
+    except Exception as exc:  # noqa: BLE001
+        print(f"[conftest] could not build the HIP library: {exc}")
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import gs2d_oracle
