@@ -591,9 +591,10 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
 // Gradient record (GS2D_GRAD_FLOATS = 20 floats per Gaussian):
 //   [0..2] dL_dcolor  [3..5] dL_dnormal  [6..14] dL_dT (Tu,Tv,Tw)  [15] dL_dopacity  [16,17] dL_dmean2D.xy
 //
-// One wave per 8x8 quadrant, waves independent (wave-private LDS staging, no workgroup barrier).  Per contributing (wave, splat) pair the 16
-// main components are reduced with the butterfly above and added with ONE global atomic instruction whose 16
-// active lanes cover 64 contiguous bytes of the Gaussian's record (the reference issues 16-18 atomics per
+// One wave per 8x8 quadrant, waves independent (wave-private LDS staging, no workgroup barrier).  Per contributing
+// (row, splat) pair the 16 main components are reduced over the row's 16 lanes with the butterfly above, added into the
+// splat's LDS accumulators, and flushed to the Gaussian's record once per (quadrant, batch) by one global atomic
+// instruction whose lanes cover four records' contiguous bytes (the reference issues 16-18 scalar atomics per
 // (pixel, splat) pair).
 // Wave-private LDS of the backward: a 64-byte staged record per splat of the batch (Tu|cx, Tv|cy, Tw|opacity,
 // r,g,b,id -- the normal is fetched from global memory only by waves that carry normal gradients) and 13 gradient
