@@ -160,8 +160,6 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     char* geom = (char*)geometry_alloc(geometry_user, GL.total);
     if (!geom) return fail_msg("geometry allocation failed");
     const ImgLayout IL = img_layout(width, height);
-    char* img = (char*)image_alloc(image_user, IL.total);
-    if (!img) return fail_msg("image allocation failed");
 
     CamParams cam;
     cam.vm = viewmatrix; cam.pm = projmatrix; cam.campos = cam_pos;
@@ -202,6 +200,9 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     // While the GPU works towards num_rendered, ask for the binning chunk already, sized from the previous call's count
     // (+12.5 %): the allocator callback (a trip through the caller's runtime) then costs nothing on the critical
     // path.  If the guess turns out too small the callback is simply invoked a second time with the exact size.
+    // (the image chunk is not needed before the tile ranges are written, so its allocator round trip also happens here)
+    char* img = (char*)image_alloc(image_user, IL.total);
+    if (!img) return fail_msg("image allocation failed");
     const size_t guess_R = (size_t)g_last_R + g_last_R / 8 + 4096;
     const size_t pre_bytes = bin_layout((int)(guess_R > 0x7fffffffull ? 0x7fffffffull : guess_R)).total;
     char* bin_pre = (char*)binning_alloc(binning_user, pre_bytes);
