@@ -10,18 +10,19 @@ import ctypes as C
 import torch
 
 from . import _lib
+from .rasterizer import _on_device, _stream_ptr
 
 
 def _call(cfg, W, H, color_, allmap_, gtc, gtd, ws, out, g_color, g_allmap, upstream, dev):
     p = lambda t: None if t is None else t.data_ptr()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = _lib.lib().gs2d_slam_loss(
             int(cfg["mode"]), W, H, color_.data_ptr(), allmap_.data_ptr(), gtc.data_ptr(), gtd.data_ptr(),
             float(cfg["w_color"]), float(cfg["w_depth"]), float(cfg.get("w_dist", 0.0)), float(cfg.get("silmask_th", 0.9)),
             float(cfg.get("edge_thres", 0.4)), int(bool(cfg.get("use_edge_growth", False))),
             int(bool(cfg.get("use_weight_norm", True))), float(cfg.get("eps", 1e-6)), float(cfg.get("depth_near", 1e-2)),
             float(cfg.get("depth_far", 1e2)), ws.data_ptr(), p(out), p(g_color), p(g_allmap), p(upstream),
-            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            _stream_ptr(dev))
     if rc < 0:
         raise RuntimeError("gs2d_slam_loss failed")
 

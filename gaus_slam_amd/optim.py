@@ -14,6 +14,7 @@ from collections import OrderedDict
 import torch
 
 from . import _lib
+from .rasterizer import _on_device, _stream_ptr
 from .ba_shard import BUCKET_FIELDS, BUCKET_FLOATS
 
 # reference name (optimizer group "name", scene/Gaussians.py:124-135) for each bucket field
@@ -76,10 +77,10 @@ class FusedGaussianAdam:
         n = len(BUCKET_FIELDS)
         ends = (C.c_ulonglong * n)(*self._group_end())
         lrs = (C.c_float * n)(*self.lr)
-        with torch.cuda.device(soa.flat.device):
+        with _on_device(soa.flat.device):
             rc = _lib.lib().gs2d_adam_step(n, ends, lrs, self.betas[0], self.betas[1], self.eps, self.step_count,
                                            soa.flat.numel(), soa.flat.data_ptr(), grad_flat.data_ptr(), self.exp_avg.data_ptr(),
-                                           self.exp_avg_sq.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                           self.exp_avg_sq.data_ptr(), _stream_ptr(soa.flat.device))
         if rc != 0:
             raise RuntimeError("gs2d_adam_step failed (bad group table or misaligned buffers)")
 

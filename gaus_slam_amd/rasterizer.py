@@ -66,8 +66,32 @@ def _chunk_alloc(user, nbytes):
 _CHUNK_CB = _lib.ALLOC_FN(_chunk_alloc)
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_ptr(device):
+    """Raw hipStream_t of torch's current stream on `device` (fast path: no Stream object is built)."""
+    if _RAW_STREAM is not None:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        return C.c_void_p(_RAW_STREAM(idx))
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` that costs nothing when `dev` already is the current device (the usual case)."""
+
+    def __init__(self, device):
+        idx = device.index
+        self.ctx = None if idx is None or idx == torch.cuda.current_device() else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
@@ -98,7 +122,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         keep = [_f32c(t) for t in (background, means3D, sh, colors, opacity, scales, rotations, transMat_precomp,
                                    viewmatrix, projmatrix, campos)]
         bg_, m3_, sh_, col_, op_, sc_, rot_, tm_, vm_, pm_, cp_ = keep
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             prt_ = _f32c(pose_Rt) if pose_Rt is not None else None
             pq_ = _f32c(pose_quat) if pose_quat is not None else None
             rendered = L.gs2d_forward_posed(
@@ -145,7 +169,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             keep = [_f32c(t) for t in (background, means3D, colors, scales, rotations, viewmatrix, projmatrix, campos,
                                        dL_dout_color, dL_dout_others, pose_Rt, pose_quat)]
             bg_, m3_, col_, sc_, rot_, vm_, pm_, cp_, dc_, do_, prt_, pq_ = keep
-            with torch.cuda.device(dev):
+            with _on_device(dev):
                 rc = L.gs2d_backward_posed(
                     P, int(degree), 0, int(R), _ptr(bg_), W, H, _ptr(m3_), None, _ptr(col_), _ptr(sc_), float(scale_modifier),
                     _ptr(rot_), None, _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy),
@@ -178,7 +202,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                    projmatrix, campos, dL_dout_color, dL_dout_others)]
         bg_, m3_, sh_, col_, sc_, rot_, tm_, vm_, pm_, cp_, dc_, do_ = keep
         radii_ = radii.contiguous()
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             prt_ = _f32c(pose_Rt) if pose_Rt is not None else None
             pq_ = _f32c(pose_quat) if pose_quat is not None else None
             dL_dpose = torch.empty((3, 4), dtype=torch.float32, device=dev) if pose_Rt is not None else None
@@ -208,7 +232,7 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
     if P != 0:
         m3_, vm_, pm_ = _f32c(means3D), _f32c(viewmatrix), _f32c(projmatrix)
-        with torch.cuda.device(means3D.device):
+        with _on_device(means3D.device):
             rc = L.gs2d_mark_visible(P, m3_.data_ptr(), vm_.data_ptr(), pm_.data_ptr(), present.data_ptr(),
                                      _stream_ptr(means3D.device))
         if rc < 0:

@@ -37,9 +37,9 @@ def pose_quaternion(pose_Rt: torch.Tensor) -> torch.Tensor:
     import ctypes as C
     from . import _lib
     q = torch.empty(4, dtype=torch.float32, device=pose_Rt.device)
-    with torch.cuda.device(pose_Rt.device):
+    with _r._on_device(pose_Rt.device):
         rc = _lib.lib().gs2d_pose_quat(pose_Rt.data_ptr(), q.data_ptr(),
-                                       C.c_void_p(torch.cuda.current_stream(pose_Rt.device).cuda_stream))
+                                       _r._stream_ptr(pose_Rt.device))
     if rc < 0:
         raise RuntimeError(_lib.last_error())
     return q
