@@ -233,7 +233,7 @@ radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __res
 // device scan -> stable scatter.  Replaces ceil(bits/8) passes of the generic 8-bit sort and yields the tile
 // ranges for free (they are the scanned histogram's tile boundaries).
 constexpr int BIN_T = 256;
-constexpr int BIN_ITEMS = 4096;             // instances per workgroup
+constexpr int BIN_ITEMS = GS2D_BIN_ITEMS;   // instances per workgroup
 constexpr int BIN_WAVE_ITEMS = BIN_ITEMS / 4;
 
 // hist[tile * nblocks + block]

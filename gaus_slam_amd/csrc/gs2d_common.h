@@ -43,7 +43,9 @@ struct ImgLayout {
 
 #define GS2D_SCAN_ITEMS 1024  // elements per workgroup in the device scan
 #define GS2D_SORT_ITEMS 2048  // elements per workgroup in one radix pass (256 threads x 8)
+#ifndef GS2D_BIN_ITEMS
 #define GS2D_BIN_ITEMS 4096   // elements per workgroup in the single-pass tile binning
+#endif
 #define GS2D_BIN_MAX_TILES 4096  // 4 waves x tiles x 4 B of LDS counters must fit 64 KB
 
 static inline GeomLayout geom_layout(int P)
