@@ -25,7 +25,7 @@ from gaus_slam_amd import _lib, ba_shard, render as gs_render  # noqa: E402
 from gaus_slam_amd.scene_synth import make_scene, make_upstream_grads, random_w2c, setup_camera  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-STAGES = ["preprocess", "scan", "duplicate", "sort", "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd"]
+STAGES = ["preprocess", "scan", "duplicate", "sort", "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "cull"]
 
 
 def stage_bytes(P, R, HW):
@@ -36,6 +36,7 @@ def stage_bytes(P, R, HW):
         "duplicate": 20 * P + 12 * R,
         "sort": 24 * R,                        # one read + one write of the 12-B pairs (a 6-pass LSD sort moves 6x)
         "ranges": 8 * R,
+        "cull": 60 * R,                        # id + 52 B of the record in, 4 B of sub-block bits out
         "blend_fwd": 84 * R + 68 * HW,         # 4-B id + 80-B record per instance; 40 B images + 28 B state per pixel
         "blend_bwd": 84 * R + 68 * HW + 72 * P,  # gather + per-pixel grads/state + accumulator write-back
         "preprocess_bwd": 152 * P + 80 * P,
@@ -170,11 +171,11 @@ def main():
         L.gs2d_stage_timing_enable(1)
         acc = [0.0] * len(STAGES)
         nrep = 10
-        buf = (C.c_float * 8)()
+        buf = (C.c_float * len(STAGES))()
         for _ in range(nrep):
             ba.local_backward(0)
             L.gs2d_stage_timing_read(buf)
-            for i in range(8):
+            for i in range(len(STAGES)):
                 acc[i] += max(buf[i], 0.0)
         L.gs2d_stage_timing_enable(0)
         stage_ms = {n: acc[i] / nrep for i, n in enumerate(STAGES)}

@@ -54,7 +54,7 @@ uint32_t higher_msb(uint32_t n)
 
 // Optional per-stage device timing (hipEvents recorded on the SAME stream the kernels are launched on).
 // Used by bench.py for the per-kernel roofline; off by default (no events are created or recorded).
-enum { ST_PREPROCESS = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_COUNT };
+enum { ST_PREPROCESS = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_CULL, ST_COUNT };
 struct StageTimer {
     bool enabled = false;
     hipEvent_t ev[ST_COUNT][2];
@@ -98,9 +98,9 @@ void gs2d_stage_timing_enable(int on)
     for (int i = 0; i < ST_COUNT; i++) g_timer.recorded[i] = false;
 }
 
-// ms[8]: preprocess, scan, duplicate, sort, ranges, blend_fwd, blend_bwd, preprocess_bwd of the most recent calls
+// ms[9]: preprocess, scan, duplicate, sort, ranges, blend_fwd, blend_bwd, preprocess_bwd, cull of the most recent calls
 // (-1 where nothing was recorded).  Synchronises on the recorded events.
-int gs2d_stage_timing_read(float ms[8])
+int gs2d_stage_timing_read(float ms[9])
 {
     for (int i = 0; i < ST_COUNT; i++) {
         ms[i] = -1.f;
@@ -272,6 +272,12 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
         gs2d::launch_tile_depth_sort(R, IL.tiles, ranges, keys, point_list, keys_alt, vals_alt, one_pass ? 1 : 0, debug ? 1 : 0, s);
         g_timer.end(ST_SORT, s);
         GS2D_STAGE("tile depth sort");
+    }
+    if (R > 0) {
+        g_timer.begin(ST_CULL, s);
+        gs2d::launch_cull(width, height, ranges, point_list, rec, hits, s);
+        g_timer.end(ST_CULL, s);
+        GS2D_STAGE("cull");
     }
     g_timer.begin(ST_BLEND_FWD, s);
     gs2d::launch_blend_fwd(width, height, ranges, point_list, rec, background, out_color, out_others, pix_state, hits,

@@ -2,28 +2,25 @@
 //
 // Semantics: RAST/cuda_rasterizer/forward.cu:258-467 and backward.cu:143-463 of the reference.
 // Design (gfx950, wave64):
-//   * one workgroup per 16x16 tile, 4 waves, each wave owns an 8x8 pixel quadrant (compact footprint ->
-//     coherent per-wave skip / early-out decisions);
-//   * the tile's depth-sorted splat list is consumed in batches of 64: each lane fetches one packed 80-byte
-//     splat record, a conservative cull test per quadrant is ballot-ed into a 64-bit mask, the records are staged
-//     in wave-private LDS and the wave walks the set bits reading them back as broadcasts, prefetched one ahead
-//     (no workgroup barrier anywhere in the loops);
-//   * forward: the 4 waves run independently (no workgroup barrier in the loop; a wave leaves as soon as
-//     its 64 pixels are saturated);
-//   * backward: per-(pixel,splat) gradients are summed over the 64 lanes with a 16-value permlane/DPP butterfly
-//     and flushed with ONE packed global atomic instruction per contributing (quadrant, splat) --
-//     the reference issues 16-18 scalar atomics per (pixel, splat).
+//   * one workgroup per 16x16 tile, 4 fully independent waves (no workgroup barrier anywhere), each wave owns an 8x8
+//     pixel quadrant and each of its 16-lane DPP rows a 4x4 sub-block;
+//   * which splats can touch which sub-block is decided once per instance by cull_kernel (gs2d_cull.hip); both kernels
+//     read those bits, fetch only the touching splats' packed records (one lane per record), stage them compacted in
+//     wave-private LDS in batches of 64 and give every row its own depth-ordered queue of slot numbers (a byte list in
+//     LDS): each loop trip the four rows composite four different splats, records read back as per-row LDS broadcasts,
+//     prefetched one trip ahead;
+//   * backward: per-(pixel,splat) gradients are summed over the 16 lanes of a row with a 16-value DPP butterfly, added
+//     into per-splat accumulators in wave-private LDS (ds_add_f32) and flushed to the Gaussian's gradient record once
+//     per (quadrant, batch) -- the reference issues 16-18 scalar global atomics per (pixel, splat).
 // Arithmetic follows the oracle's expression order; the file is compiled with -ffp-contract=off so the
-// per-pixel recurrences reproduce the CPU oracle up to the ulp-level difference of expf.
+// per-pixel recurrences reproduce the CPU oracle up to the ulp-level difference of v_exp_f32 / v_rcp_f32.
 #include "gs2d_common.h"
+
+#include <type_traits>
 
 namespace {
 
 // ------------------------------------------------------------------------------------------- helpers
-__device__ __forceinline__ float bcast(float v, int lane)  // wave-uniform broadcast of lane `lane` (v_readlane_b32)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
-}
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }          // v_rcp_f32, 1 ulp
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }         // v_sqrt_f32, 1 ulp
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }  // v_exp_f32
@@ -31,97 +28,6 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 // with rounding, so these return exactly fast_exp(-0.5f * r) / fast_exp(-(q * 0.25f)) with one multiply less.
 __device__ __forceinline__ float fast_exp_neg_half(float r) { return __builtin_amdgcn_exp2f(r * -0.72134752044448170368f); }
 __device__ __forceinline__ float fast_exp_neg_quarter(float q) { return __builtin_amdgcn_exp2f(q * -0.36067376022224085184f); }
-
-// Conservative test "can this splat reach alpha >= 1/255 on any pixel of a pixel rectangle?", applied to the four
-// 4x4 sub-blocks of a wave's 8x8 quadrant,
-// evaluated by the lane that holds the splat record.  rho_max = 2 ln(255 opacity) (+margin, precomputed by the
-// preprocess kernel):   alpha >= 1/255  <=>  min(rho3d, rho2d) <= rho_max.
-//  (1) {rho2d <= rho_max} is a disc of radius sqrt(rho_max/100) px around the stored centre.
-//  (2) {rho3d <= rho_max} is the image of the disc u^2+v^2 <= rho_max of the surfel.  When that disc lies safely
-//      in front of the eye the image is an ellipse; its exact AABB follows from the closed form the reference uses
-//      for its 3-sigma box (forward.cu:119-147) with cutoff^2 = rho_max.
-//  (3) Inside the AABB the ellipse itself is tested: with k = x Tw - Tu, l = y Tw - Tv the kernel's p = k x l is
-//      LINEAR in the pixel, p = A dx + B dy + C (A = Tw x l, B = k x Tw, C = k x l at the rectangle centre), so
-//      F = p.x^2 + p.y^2 - rho_max p.z^2 is an exact quadratic whose sign is the sign of rho3d - rho_max.  For a
-//      convex F the minimum over the rectangle lies at the ellipse centre (if inside) or on one of the 4 edges,
-//      where F is a 1-D parabola.  The splat is dropped only if that minimum exceeds a rounding margin.
-// Anything that cannot be bounded safely is kept.  Culling therefore never changes a result: a culled pair is one
-// the reference would have `continue`d past (tests: bit-exact n_contrib on a stress scene).
-// Returns a 4-bit mask: bit r set = the splat may reach alpha >= 1/255 on 4x4 sub-block r of the 8x8 quadrant whose
-// first pixel is (qx, qy)  (sub-block r covers x in [qx + 4(r&1), +3], y in [qy + 4(r>>1), +3]).
-__device__ __forceinline__ uint32_t splat_touch_mask(const float4 q0, const float4 q1, const float4 q2, float rho_max,
-                                                     float qx, float qy)
-{
-    if (!(rho_max >= 0.f)) return 0u;  // opacity*G can never reach 1/255 (NaN opacity is encoded as +huge)
-    const float x0 = qx, x1 = qx + 7.f, y0 = qy, y1 = qy + 7.f;
-    const float rl = fast_sqrt(rho_max * (1.0f / GS2D_FILTER_INV_SQ)) + 0.5f;  // cull-only math: hardware sqrt/rcp, margins cover the ulps
-    // low-pass disc {rho2d <= rho_max}: bounding box of the disc per sub-block
-    uint32_t lp = 0u;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const float sx0 = qx + 4.f * (r & 1), sy0 = qy + 4.f * (r >> 1);
-        if (!(q0.w + rl < sx0 || q0.w - rl > sx0 + 3.f || q1.w + rl < sy0 || q1.w - rl > sy0 + 3.f)) lp |= 1u << r;
-    }
-    const float a = rho_max * (q2.x * q2.x + q2.y * q2.y), zz = q2.z * q2.z;
-    if (!(a <= 0.9f * zz) || !(q2.z > 0.f)) return 0xFu;  // disc not safely in front of the eye: no bound
-    const float inv = fast_rcp(a - zz);
-    const float f0 = rho_max * inv, f2 = -inv;
-    const float cx = f0 * (q0.x * q2.x + q0.y * q2.y) + f2 * (q0.z * q2.z);
-    const float cy = f0 * (q1.x * q2.x + q1.y * q2.y) + f2 * (q1.z * q2.z);
-    const float hx = cx * cx - (f0 * (q0.x * q0.x + q0.y * q0.y) + f2 * (q0.z * q0.z));
-    const float hy = cy * cy - (f0 * (q1.x * q1.x + q1.y * q1.y) + f2 * (q1.z * q1.z));
-    if (!(hx == hx) || !(hy == hy)) return 0xFu;
-    const float ex = fast_sqrt(fmaxf(hx, 0.f)), ey = fast_sqrt(fmaxf(hy, 0.f));
-    const float mx = 0.5f + 0.02f * ex + 1e-4f * fabsf(cx), my = 0.5f + 0.02f * ey + 1e-4f * fabsf(cy);
-    if (cx + ex + mx < x0 || cx - ex - mx > x1 || cy + ey + my < y0 || cy - ey - my > y1) return lp;  // AABB misses the quadrant
-    // exact conic in coordinates local to the quadrant centre (|dx|,|dy| <= 3.5: well conditioned)
-    const float xm = qx + 3.5f, ym = qy + 3.5f;
-    const float k0 = fmaf(xm, q2.x, -q0.x), k1 = fmaf(xm, q2.y, -q0.y), k2 = fmaf(xm, q2.z, -q0.z);
-    const float l0 = fmaf(ym, q2.x, -q1.x), l1 = fmaf(ym, q2.y, -q1.y), l2 = fmaf(ym, q2.z, -q1.z);
-    const float Cx = k1 * l2 - k2 * l1, Cy = k2 * l0 - k0 * l2, Cz = k0 * l1 - k1 * l0;          // k x l
-    const float Ax = q2.y * l2 - q2.z * l1, Ay = q2.z * l0 - q2.x * l2, Az = q2.x * l1 - q2.y * l0;  // Tw x l
-    const float Bx = k1 * q2.z - k2 * q2.y, By = k2 * q2.x - k0 * q2.z, Bz = k0 * q2.y - k1 * q2.x;  // k x Tw
-    const float c = rho_max;
-    const float Fxx = Ax * Ax + Ay * Ay - c * (Az * Az), Fyy = Bx * Bx + By * By - c * (Bz * Bz);
-    const float Fxy = Ax * Bx + Ay * By - c * (Az * Bz);
-    const float Fx = Ax * Cx + Ay * Cy - c * (Az * Cz), Fy = Bx * Cx + By * Cy - c * (Bz * Cz);
-    const float F0 = Cx * Cx + Cy * Cy - c * (Cz * Cz);
-    if (!(Fxx > 0.f) || !(Fyy > 0.f)) return 0xFu;  // not the convex (ellipse) case after rounding: keep
-    // rounding margin: 1e-4 of the largest magnitude the terms of F can reach on the quadrant
-    const float Px = (fabsf(Ax) + fabsf(Bx)) * 3.5f + fabsf(Cx), Py = (fabsf(Ay) + fabsf(By)) * 3.5f + fabsf(Cy);
-    const float Pz = (fabsf(Az) + fabsf(Bz)) * 3.5f + fabsf(Cz);
-    const float margin = 1e-4f * (Px * Px + Py * Py + c * (Pz * Pz));
-    const float iFxx = fast_rcp(Fxx), iFyy = fast_rcp(Fyy);
-    uint32_t m = lp;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        // sub-block r in local coordinates: dx in [xa, xa+3], dy in [ya, ya+3]
-        const float xa = (r & 1) ? 0.5f : -3.5f, ya = (r >> 1) ? 0.5f : -3.5f;
-        const float xb = xa + 3.f, yb = ya + 3.f;
-        const float sx0 = qx + 4.f * (r & 1), sy0 = qy + 4.f * (r >> 1);
-        // AABB of the ellipse vs the sub-block
-        if (cx + ex + mx < sx0 || cx - ex - mx > sx0 + 3.f || cy + ey + my < sy0 || cy - ey - my > sy0 + 3.f) continue;
-        // ellipse centre inside (or within the margin of) the sub-block: certainly touching
-        bool t = !(cx + mx < sx0 || cx - mx > sx0 + 3.f || cy + my < sy0 || cy - my > sy0 + 3.f);
-        if (!t) {
-            float fmin_edges = 3.0e38f;
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const float dy = e ? yb : ya;  // horizontal edges: F(t, dy) = Fxx t^2 + 2 b t + cq
-                const float bq = fmaf(Fxy, dy, Fx), cq = fmaf(fmaf(Fyy, dy, 2.f * Fy), dy, F0);
-                const float tt = fminf(fmaxf(-bq * iFxx, xa), xb);
-                fmin_edges = fminf(fmin_edges, fmaf(fmaf(Fxx, tt, 2.f * bq), tt, cq));
-                const float dx = e ? xb : xa;  // vertical edges: F(dx, t) = Fyy t^2 + 2 b2 t + cq2
-                const float b2 = fmaf(Fxy, dx, Fy), cq2 = fmaf(fmaf(Fxx, dx, 2.f * Fx), dx, F0);
-                const float t2 = fminf(fmaxf(-b2 * iFyy, ya), yb);
-                fmin_edges = fminf(fmin_edges, fmaf(fmaf(Fyy, t2, 2.f * b2), t2, cq2));
-            }
-            t = !(fmin_edges > margin);  // NaN -> keep
-        }
-        if (t) m |= 1u << r;
-    }
-    return m;
-}
 
 // Part A of the per-(pixel, splat) work: ray-splat intersection and alpha (forward.cu:360-387; FMA form identical
 // to oracle/gs2d_oracle.c).  Branch-free; `ok` folds the reference's skip tests in their original order
@@ -146,12 +52,7 @@ __device__ __forceinline__ void fwd_eval(const float4 q0, const float4 q1, const
     ok = !(p2 == 0.0f) && !(depth < GS2D_NEAR_N) && !(rho < 0.0f) && !(alpha < 1.0f / 255.0f);
 }
 
-// Wave-private LDS staging of one 64-splat batch: lane i writes record i, any lane reads record j as a
-// same-address broadcast (conflict-free).  LDS operations of one wave execute in order; the fence only stops
-// the compiler from reordering them.
-struct WaveBatch {
-    float4 q[GS2D_REC_F4][64];
-};
+// Wave-private LDS: operations of one wave execute in order; the fence only stops the compiler from reordering them.
 __device__ __forceinline__ void wave_lds_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -162,6 +63,9 @@ __device__ __forceinline__ void wave_lds_sync()
 #ifndef GS2D_WAVES_PER_EU
 #define GS2D_WAVES_PER_EU 5  // 96 VGPRs: all 1200 tiles of a 640x480 frame resident at once (5 workgroups per CU)
 #endif
+#ifndef GS2D_FWD_WAVES_PER_EU
+#define GS2D_FWD_WAVES_PER_EU GS2D_WAVES_PER_EU
+#endif
 // Dev-only experiment hooks (scripts/dev/variants.sh builds variants with -DGS2D_EXPERIMENT=n; results are WRONG by
 // design, they only price one ingredient of blend_bwd via scripts/dev/stage_ms.py).  All pass-through in the product
 // build.  1: no global atomics in the flush   2: no butterfly   4: no flush loop   5: plain LDS store instead of ds_add_f32
@@ -171,7 +75,7 @@ __device__ __forceinline__ void wave_lds_sync()
 #define GS2D_EXP_ATOMIC(X) X
 #endif
 #if defined(GS2D_EXPERIMENT) && GS2D_EXPERIMENT == 4
-#define GS2D_EXP_FLUSH(T) ((T) == 12345ull)
+#define GS2D_EXP_FLUSH(T) ((T) && f0 == 12345)
 #else
 #define GS2D_EXP_FLUSH(T) (T)
 #endif
@@ -188,28 +92,25 @@ __device__ __forceinline__ void wave_lds_sync()
 #ifdef GS2D_PROFILE_WAVES
 // dev-only instrumentation (scripts/dev/wave_profile.py): per wave [start, end, trips, hw_id] for the last launch
 __device__ unsigned long long g_wave_prof[2][4 * 8192 * 4];
-#define GS2D_PROF_BEGIN() const unsigned long long prof_t0 = wall_clock64(); unsigned int prof_trips = 0
+#define GS2D_PROF_BEGIN() const unsigned long long prof_t0 = wall_clock64(); unsigned int prof_trips = 0; unsigned long long prof_stage = 0, prof_s0 = 0
 #define GS2D_PROF_TRIP() prof_trips++
+#define GS2D_PROF_STAGE_BEGIN() prof_s0 = __builtin_amdgcn_s_memtime()
+#define GS2D_PROF_STAGE_END() prof_stage += __builtin_amdgcn_s_memtime() - prof_s0
 #define GS2D_PROF_END(K)                                                                                             \
     if (lane == 0 && blockIdx.x < 8192) {                                                                            \
         unsigned long long* pp = g_wave_prof[K] + ((size_t)blockIdx.x * 4 + wave) * 4;                               \
-        pp[0] = prof_t0; pp[1] = wall_clock64(); pp[2] = prof_trips;                                                 \
+        pp[0] = prof_t0; pp[1] = wall_clock64(); pp[2] = prof_trips | (prof_stage << 32); /* staging time in shader cycles */                                                 \
         pp[3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); \
     }
 #else
 #define GS2D_PROF_BEGIN()
 #define GS2D_PROF_TRIP()
+#define GS2D_PROF_STAGE_BEGIN()
+#define GS2D_PROF_STAGE_END()
 #define GS2D_PROF_END(K)
 #endif
 
-// ------------------------------------------------------------------------------------------- forward
-// One wave per 8x8 pixel quadrant, 4 independent waves per 16x16 tile; inside the wave each 16-lane DPP row owns
-// one 4x4 sub-block.  Per 64-splat batch: lane i fetches record i, tests it against the four sub-blocks
-// (splat_touch_mask) and stages it in wave-private LDS; the four ballots of the mask bits are four depth-ordered
-// QUEUES, one per sub-block.  Every loop trip row r pops the next splat of ITS queue and reads that record from LDS
-// (per-row address, 5 x ds_read_b128, software-pipelined one trip ahead), so the four rows composite four different
-// splats at once: per-pixel order is untouched (a splat that touches several sub-blocks sits in several queues), the
-// trip count is the LONGEST queue instead of the whole list, and the VALU executes only per-pixel math.
+// ------------------------------------------------------------------------------------------- queue helpers
 __device__ __forceinline__ int row_select(int row8, int j0, int j1, int j2, int j3)
 {
     // j0..j3 are wave-uniform (<= 64): pack them into one scalar and let every lane extract its row's byte with a single
@@ -233,10 +134,26 @@ __device__ __forceinline__ int pop_back(uint64_t& m)
     return j;
 }
 
+// ------------------------------------------------------------------------------------------- forward
+// One wave per 8x8 pixel quadrant, 4 independent waves per 16x16 tile; inside the wave each 16-lane DPP row owns
+// one 4x4 sub-block.  The tile's depth-sorted list is read in 64-instance chunks; the cull bits of this quadrant
+// (cull_kernel, gs2d_cull.hip) say which splats touch which sub-block, so only touching splats are fetched and staged,
+// compacted, in wave-private LDS until the 64 slots of a BATCH are full.  Each sub-block (= DPP row) then gets its own
+// depth-ordered QUEUE of slot numbers -- a byte list in LDS, built once per batch with ballot + mbcnt -- and every loop
+// trip row r reads the next entry of ITS queue and that splat's record (per-row address, 5 x ds_read_b128,
+// software-pipelined one trip ahead; the queue entries two trips ahead), so the four rows composite four different
+// splats at once: per-pixel order is untouched (a splat that touches several sub-blocks sits in several queues), the
+// trip count is the LONGEST queue instead of the whole list, the VALU executes only per-pixel math and the scalar unit
+// only the loop counter (round 1 popped 64-bit bit-queues with ~65 scalar instructions per trip).
+struct FwdBatch {
+    float4 q[GS2D_REC_F4][64];  // staged records, SoA by quarter
+    uint8_t ql[4][64];          // per-row queues: slot numbers in depth order
+    uint32_t tail[4];           // the pipeline reads up to two entries past a full queue (values unused)
+};
+
 // XCD-aware workgroup -> tile mapping.  Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own
 // L2.  Handing XCD x the x-th contiguous band of tiles (row-major) keeps the tiles a Gaussian touches on ONE XCD in all
-// but the band-border cases, so its gradient record is accumulated by atomics in a single L2 instead of bouncing
-// between the L2s of neighbouring tiles' XCDs (measured: ~30% of the backward), and record gathers hit in L2.
+// but the band-border cases, so record gathers hit in that L2.
 // Purely a placement heuristic: any dispatch order gives the same results.
 #define GS2D_XCDS 8
 __device__ __forceinline__ int xcd_tile(int block, int ntiles)
@@ -247,18 +164,24 @@ __device__ __forceinline__ int xcd_tile(int block, int ntiles)
     return tile < ntiles ? tile : -1;  // the last band may be short
 }
 
+// lane's position among the set bits of a ballot below it
+__device__ __forceinline__ int rank_below(uint64_t b)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+}
+
 template <bool USE_SA>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS2D_WAVES_PER_EU, GS2D_WAVES_PER_EU)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS2D_FWD_WAVES_PER_EU, GS2D_FWD_WAVES_PER_EU)))
 blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
-                 float* __restrict__ out_others, float* __restrict__ pix_state, size_t plane, uint8_t* __restrict__ hits)
+                 float* __restrict__ out_others, float* __restrict__ pix_state, size_t plane, const uint8_t* __restrict__ hits)
 {
-    __shared__ WaveBatch batches[4];
+    __shared__ FwdBatch batches[4];
     const int tile = xcd_tile(blockIdx.x, ntiles);
     if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    WaveBatch& wb = batches[wave];
+    FwdBatch& wb = batches[wave];
     const int qx0 = tx * GS2D_TILE + (wave & 1) * 8, qy0 = ty * GS2D_TILE + (wave >> 1) * 8;
     const int row = lane >> 4, li = lane & 15;                       // DPP row = 4x4 sub-block
     const int row8 = row * 8;
@@ -268,6 +191,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     const float pxf = (float)px, pyf = (float)py;
     const uint2 range = ranges[tile];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const uint8_t* qrow = wb.ql[row];
 
     float T = 1.0f, C0_ = 0.f, C1_ = 0.f, C2_ = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
     float Dp = 0.f, M1 = 0.f, M2 = 0.f, D2 = 0.f, distortion = 0.f, median_depth = 0.f;
@@ -276,10 +200,9 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     bool done = !inside;
     GS2D_PROF_BEGIN();
 
-    // Batches are COMPACTED (see the backward for the rationale): the list is read in 64-instance chunks, every lane
-    // culls one splat, but only the splats that touch this quadrant are staged, and chunks keep being added until the 64
-    // LDS slots are full.  A chunk that does not fit is split: the lanes left over keep their cull bits (carry_tm) and
-    // are staged first in the next batch (their records are simply fetched again).
+    // Batches are COMPACTED: the list is read in 64-instance chunks, but only the splats whose cull bits touch this
+    // quadrant are fetched and staged, and chunks keep being added until the 64 LDS slots are full.  A chunk that does not
+    // fit is split: the lanes left over keep their cull bits (carry_tm) and are staged first in the next batch.
     uint32_t next_chunk = range.x;  // absolute index of the next chunk to read
     uint32_t carry_base = 0;
     uint32_t carry_tm = 0u;
@@ -287,33 +210,26 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     for (;;) {
         if (__ballot(!done) == 0) break;
         int fill = 0;
+        GS2D_PROF_STAGE_BEGIN();
         wave_lds_sync();  // previous batch fully consumed before it is overwritten
         for (;;) {
-            uint32_t cbase, tm = 0u;
-            bool fresh;
-            if (carry) { cbase = carry_base; tm = carry_tm; carry = false; fresh = false; }
+            uint32_t cbase, tm;
+            if (carry) { cbase = carry_base; tm = carry_tm; carry = false; }
             else {
                 if (next_chunk >= range.y) break;
-                cbase = next_chunk; next_chunk += 64; fresh = true;
-            }
-            const bool need = fresh ? (cbase + lane < range.y) : (tm != 0u);
-            float4 r0, r1, r2, r3, r4;
-            if (need) {
-                const uint32_t id = point_list[cbase + lane];
-                const float4* rp = rec + (size_t)id * GS2D_REC_F4;
-                r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4];
-                if (fresh) {
-                    tm = splat_touch_mask(r0, r1, r2, r4.z, (float)qx0, (float)qy0);
-                    // one byte per (instance, quadrant): the backward rebuilds its row queues from these bits
-                    hits[(size_t)(cbase + lane) * 4 + wave] = (uint8_t)tm;
-                }
+                cbase = next_chunk; next_chunk += 64;
+                tm = cbase + lane < range.y ? hits[(size_t)(cbase + lane) * 4 + wave] : 0u;
             }
             const uint64_t tb = __ballot(tm != 0u);
             const int c = __popcll(tb);
             if (c == 0) continue;
-            const int slot = fill + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(tb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tb, 0u));
+            const int slot = fill + rank_below(tb);
             const bool take = tm != 0u && slot < 64;
             if (take) {
+                const uint32_t id = point_list[cbase + lane];
+                const float4* rp = rec + (size_t)id * GS2D_REC_F4;
+                const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+                float4 r4 = rp[4];
                 r4.w = __uint_as_float(((cbase - range.x + lane) << 4) | tm);  // list position + cull bits ride in the free slot
                 wb.q[0][slot] = r0; wb.q[1][slot] = r1; wb.q[2][slot] = r2; wb.q[3][slot] = r3; wb.q[4][slot] = r4;
             }
@@ -323,30 +239,35 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
         }
         if (fill == 0) break;  // list exhausted
         wave_lds_sync();
+        // the four row queues: slot numbers of the splats whose bit r is set, in slot (= depth) order
         const uint32_t nib = lane < fill ? __float_as_uint(wb.q[4][lane].w) : 0u;
-        uint64_t m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u), m2 = __ballot(nib & 4u), m3 = __ballot(nib & 8u);
-        // software pipeline: the records of the NEXT trip are fetched from LDS while the current ones are evaluated;
-        // unrolled by two with the two register sets swapping roles (no copies).
-        int j;
-        {
-            const int j0 = pop_front(m0), j1 = pop_front(m1), j2 = pop_front(m2), j3 = pop_front(m3);
-            j = row_select(row8, j0, j1, j2, j3);
-        }
-        float4 a0 = wb.q[0][j & 63], a1 = wb.q[1][j & 63], a2 = wb.q[2][j & 63], a3 = wb.q[3][j & 63], a4 = wb.q[4][j & 63];
+        const uint64_t m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u), m2 = __ballot(nib & 4u), m3 = __ballot(nib & 8u);
+        if (nib & 1u) wb.ql[0][rank_below(m0)] = (uint8_t)lane;
+        if (nib & 2u) wb.ql[1][rank_below(m1)] = (uint8_t)lane;
+        if (nib & 4u) wb.ql[2][rank_below(m2)] = (uint8_t)lane;
+        if (nib & 8u) wb.ql[3][rank_below(m3)] = (uint8_t)lane;
+        const int len0 = __popcll(m0), len1 = __popcll(m1), len2 = __popcll(m2), len3 = __popcll(m3);
+        const int trips = max(max(len0, len1), max(len2, len3));  // >= 1: every staged splat touches some row
+        const int mylen = row_select(row8, len0, len1, len2, len3);
+        wave_lds_sync();
+        GS2D_PROF_STAGE_END();
+        // software pipeline: the records of the NEXT trip are fetched from LDS while the current ones are evaluated (queue
+        // entries one trip further ahead); unrolled by two with the two register sets swapping roles (no copies).
+        int t = 0;
+        uint32_t ja = qrow[0], jb = qrow[1];
+        float4 a0 = wb.q[0][ja & 63], a1 = wb.q[1][ja & 63], a2 = wb.q[2][ja & 63], a3 = wb.q[3][ja & 63], a4 = wb.q[4][ja & 63];
         float4 b0, b1, b2, b3, b4;
-#define GS2D_FWD_STEP(C0, C1, C2, C3, C4, N0_, N1_, N2_, N3_, N4_)                                                   \
+#define GS2D_FWD_STEP(C0, C1, C2, C3, C4, N0_, N1_, N2_, N3_, N4_, JN, JNN)                                          \
         {                                                                                                            \
             GS2D_PROF_TRIP();                                                                                        \
-            const bool more = (m0 | m1 | m2 | m3) != 0;                                                              \
-            const int nj0 = pop_front(m0), nj1 = pop_front(m1), nj2 = pop_front(m2), nj3 = pop_front(m3);            \
-            const int jn = row_select(row8, nj0, nj1, nj2, nj3);                                                     \
-            N0_ = wb.q[0][jn & 63]; N1_ = wb.q[1][jn & 63]; N2_ = wb.q[2][jn & 63]; N3_ = wb.q[3][jn & 63];          \
-            N4_ = wb.q[4][jn & 63];                                                                                  \
+            N0_ = wb.q[0][JN & 63]; N1_ = wb.q[1][JN & 63]; N2_ = wb.q[2][JN & 63]; N3_ = wb.q[3][JN & 63];          \
+            N4_ = wb.q[4][JN & 63];                                                                                  \
+            JNN = qrow[t + 2];                                                                                       \
             float alpha, depth;                                                                                      \
             bool ok;                                                                                                 \
             fwd_eval(C0, C1, C2, pxf, pyf, alpha, depth, ok);                                                        \
             const float test_T = T * (1 - alpha);                                                                    \
-            const bool pass = ok && !done && j < 64; /* j == 64: this row's queue is exhausted */                    \
+            const bool pass = ok && !done && t < mylen; /* t >= mylen: this row's queue is exhausted */              \
             const bool stop = pass && test_T < 0.0001f;                                                              \
             done = done || stop;                                                                                     \
             if (pass && !stop) {                                                                                     \
@@ -377,12 +298,11 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                 T = test_T;                                                                                          \
                 last_contributor = contributor;                                                                      \
             }                                                                                                        \
-            if (!more || __ballot(!done) == 0) break;                                                                \
-            j = jn;                                                                                                  \
+            if (++t >= trips || __ballot(!done) == 0) break;                                                         \
         }
         for (;;) {
-            GS2D_FWD_STEP(a0, a1, a2, a3, a4, b0, b1, b2, b3, b4)
-            GS2D_FWD_STEP(b0, b1, b2, b3, b4, a0, a1, a2, a3, a4)
+            GS2D_FWD_STEP(a0, a1, a2, a3, a4, b0, b1, b2, b3, b4, jb, ja)
+            GS2D_FWD_STEP(b0, b1, b2, b3, b4, a0, a1, a2, a3, a4, ja, jb)
         }
 #undef GS2D_FWD_STEP
     }
@@ -413,43 +333,6 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
 }
 
 // ------------------------------------------------------------------------------------------ backward
-// Plain 64-lane sum, total valid in lane 63 (used only on the rare low-pass branch).
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
-{
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
-    return v;
-}
-
-// --- 16-value butterfly: sums 16 per-lane values over the 64 lanes in ~35 VALU ops instead of 16 x 6.
-// Each step halves the number of live registers: lanes keep one half of the values and receive the partner's
-// partial sums for that half.  Steps: v_permlane32_swap (lane ^ 32), v_permlane16_swap (row pairs), then DPP
-// row_mirror / row_half_mirror / quad_perm inside a row.
-// v_permlane32_swap / v_permlane16_swap via inline asm: the ROCm 7.2 builtins drop their second result
-// (scripts/dev/swap_probe.hip).  hipcc inserts no wait states around asm statements, so each level issues all of
-// its (independent) swaps inside ONE asm block with the hazard nops at the block boundaries only.
-__device__ __forceinline__ void swap32_x8(float v[16])  // pairs (v[2i], v[2i+1]): v[2i].hi <-> v[2i+1].lo
-{
-    asm("s_nop 1\n\t"
-        "v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\t"
-        "v_permlane32_swap_b32 %6, %7\n\tv_permlane32_swap_b32 %8, %9\n\tv_permlane32_swap_b32 %10, %11\n\t"
-        "v_permlane32_swap_b32 %12, %13\n\tv_permlane32_swap_b32 %14, %15\n\t"
-        "s_nop 1"
-        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
-          "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
-}
-__device__ __forceinline__ void swap16_x4(float c[8])  // pairs (c[2i], c[2i+1]): odd rows of c[2i] <-> even rows of c[2i+1]
-{
-    asm("s_nop 1\n\t"
-        "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
-        "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
-        "s_nop 1"
-        : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
-}
 template <int CTRL>
 __device__ __forceinline__ float dpp_get(float v)
 {
@@ -462,34 +345,7 @@ __device__ __forceinline__ float seladd(float a, float b, bool hi)
     const float keep = hi ? b : a, give = hi ? a : b;
     return keep + dpp_get<CTRL>(give);
 }
-// After reduce16 every lane l holds the 64-lane total of value number
-//   idx(l) = 8*bit2(l) + 4*bit3(l) + 2*bit4(l) + bit5(l)        (bits 0,1 of l are don't-care)
-__device__ __forceinline__ float reduce16(const float vin[16], int lane)
-{
-    float v[16], c[8], d[4], e[2];
-#pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = vin[i];
-    swap32_x8(v);  // lanes 0-31 now hold both halves of v[2i], lanes 32-63 both halves of v[2i+1]
-#pragma unroll
-    for (int i = 0; i < 8; i++) c[i] = v[2 * i] + v[2 * i + 1];
-    swap16_x4(c);
-#pragma unroll
-    for (int i = 0; i < 4; i++) d[i] = c[2 * i] + c[2 * i + 1];
-    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
-    e[0] = seladd<0x140>(d[0], d[1], b3);  // row_mirror: l <-> 15-l flips bit 3
-    e[1] = seladd<0x140>(d[2], d[3], b3);
-    float f = seladd<0x141>(e[0], e[1], b2);  // row_half_mirror: l <-> 7-l flips bit 2
-    f += dpp_get<0x4E>(f);                    // quad_perm [2,3,0,1]
-    f += dpp_get<0xB1>(f);                    // quad_perm [1,0,3,2]
-    return f;
-}
-// value number held by lane l after reduce16
-__device__ __forceinline__ int reduce16_index(int lane)
-{
-    return 8 * ((lane >> 2) & 1) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
-}
-
-// --- the same butterfly inside ONE 16-lane DPP row: 16 values summed over the row's 16 lanes in 45 VALU ops; lane l of
+// --- 16-value butterfly inside ONE 16-lane DPP row: 16 values summed over the row's 16 lanes in 45 VALU ops; lane l of
 // every row ends up with value number 8*bit0(l) + 4*bit1(l) + 2*bit2(l) + bit3(l) of ITS row, so the four rows of a wave
 // reduce four different splats at once (scripts/dev/reduce16_row_probe.hip).
 __device__ __forceinline__ float reduce16_row(const float v[16], int lane)
@@ -607,7 +463,9 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
 struct BwdBatch {
     float4 q[4][64];
     float acc[64 * GS2D_ACC];
-    uint32_t pn[64];  // list position << 4 | cull bits of the staged splat
+    uint32_t pn[64];    // list position << 4 | cull bits of the staged splat
+    uint8_t ql[4][64];  // per-row queues: slot numbers, deepest first
+    uint32_t tail[4];   // the pipeline reads up to two entries past a full queue (values unused)
 };
 
 template <bool USE_SA>
@@ -626,6 +484,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     const int qx0 = tx * GS2D_TILE + (wave & 1) * 8, qy0 = ty * GS2D_TILE + (wave >> 1) * 8;
     const int row = lane >> 4, li = lane & 15;                       // DPP row = 4x4 sub-block (same mapping as the forward)
     const int row8 = row * 8;
+    const uint8_t* qrow = wb.ql[row];
     const int px = qx0 + (row & 1) * 4 + (li & 3), py = qy0 + (row >> 1) * 4 + (li >> 2);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
@@ -690,12 +549,18 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     // relatively less, untouched records are never loaded, and there are fewer batch prologues and flushes.
     // Slots are handed out from 63 downwards, deepest splat first, so a queue popped from its highest bit walks the
     // splats back to front exactly as before.
+    // The body is instantiated twice, with and without gradients on the normal channels, and the wave picks one: in the
+    // usual case (no normal loss) nine per-pixel registers (dn, last normal, normal accumulators) are never live, which is
+    // what keeps the loop inside the 96-VGPR budget of five waves per SIMD.
+    GS2D_PROF_BEGIN();
+    auto run = [&](auto dn_tag) __attribute__((always_inline)) {
+    constexpr bool ANY_DN = decltype(dn_tag)::value;
     int chunk = (int)((max_last + 63) / 64) - 1;  // next chunk to read
     int carry_chunk = -1;                           // chunk whose shallower part is still waiting
     uint32_t carry_tm = 0u;
-    GS2D_PROF_BEGIN();
     for (;;) {
         int fill = 0;
+        GS2D_PROF_STAGE_BEGIN();
         wave_lds_sync();  // previous batch fully consumed before it is overwritten
         for (;;) {
             uint32_t tm;
@@ -732,26 +597,33 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
         }
         if (fill == 0) break;  // list exhausted
         wave_lds_sync();
-        // four depth-ordered queues (bit = slot), one per 4x4 sub-block (= DPP row), walked back to front
+        // four depth-ordered queues, one per 4x4 sub-block (= DPP row): byte lists of slot numbers, deepest (= highest
+        // slot) first, so walking a list front to back visits the row's splats back to front
         const uint32_t nib = lane >= 64 - fill ? wb.pn[lane] : 0u;
-        uint64_t m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u), m2 = __ballot(nib & 4u), m3 = __ballot(nib & 8u);
-        int j;
-        {
-            const int j0 = pop_back(m0), j1 = pop_back(m1), j2 = pop_back(m2), j3 = pop_back(m3);
-            j = row_select(row8, j0, j1, j2, j3);
-        }
+        const uint64_t m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u), m2 = __ballot(nib & 4u), m3 = __ballot(nib & 8u);
+        const int len0 = __popcll(m0), len1 = __popcll(m1), len2 = __popcll(m2), len3 = __popcll(m3);
+        if (nib & 1u) wb.ql[0][len0 - 1 - rank_below(m0)] = (uint8_t)lane;
+        if (nib & 2u) wb.ql[1][len1 - 1 - rank_below(m1)] = (uint8_t)lane;
+        if (nib & 4u) wb.ql[2][len2 - 1 - rank_below(m2)] = (uint8_t)lane;
+        if (nib & 8u) wb.ql[3][len3 - 1 - rank_below(m3)] = (uint8_t)lane;
+        const int trips = max(max(len0, len1), max(len2, len3));  // >= 1: every staged splat touches some row
+        const int mylen = row_select(row8, len0, len1, len2, len3);
+        wave_lds_sync();
+        GS2D_PROF_STAGE_END();
+        // software pipeline: queue entries are read two trips ahead, records one trip ahead
+        int t = 0;
+        uint32_t j = qrow[0], jx = qrow[1];
         float4 ga0 = wb.q[0][j & 63], ga1 = wb.q[1][j & 63], ga2 = wb.q[2][j & 63];
         uint32_t gap = wb.pn[j & 63], gbp;
         float4 gb0, gb1, gb2;
-#define GS2D_BWD_STEP(G0, G1, G2, GP, N0_, N1_, N2_, NP_)                                                                    \
+#define GS2D_BWD_STEP(G0, G1, G2, GP, J, N0_, N1_, N2_, NP_, JN)                                                                  \
         {                                                                                                             \
             GS2D_PROF_TRIP();                                                                                         \
-            const bool more = (m0 | m1 | m2 | m3) != 0;                                                               \
-            const int jn = row_select(row8, pop_back(m0), pop_back(m1), pop_back(m2), pop_back(m3));                  \
-            N0_ = wb.q[0][jn & 63]; N1_ = wb.q[1][jn & 63]; N2_ = wb.q[2][jn & 63]; NP_ = wb.pn[jn & 63];             \
-            const float4 cc = wb.q[3][j & 63]; /* r, g, b, id */                                                      \
+            const uint32_t jnn = qrow[t + 2];                                                                         \
+            N0_ = wb.q[0][JN & 63]; N1_ = wb.q[1][JN & 63]; N2_ = wb.q[2][JN & 63]; NP_ = wb.pn[JN & 63];             \
+            const float4 cc = wb.q[3][J & 63]; /* r, g, b, id */                                                      \
             const uint32_t contributor = GP >> 4; /* list position, 0-based, as in backward.cu:285 */                 \
-            bool active = inside && j < 64 && contributor < last_contributor; /* j == 64: row queue exhausted */      \
+            bool active = inside && t < mylen && contributor < last_contributor; /* t >= mylen: row queue exhausted */ \
             if (__ballot(active) != 0) {                                                                              \
                 /* Part A (all lanes): same geometry / alpha as the forward */                                        \
                 const float k0 = fmaf(pxf, G2.x, -G0.x), k1 = fmaf(pxf, G2.y, -G0.y), k2 = fmaf(pxf, G2.z, -G0.z);    \
@@ -816,7 +688,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                     dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);                                    \
                     accum_alpha_rec = fmaf(1.f - last_alpha, accum_alpha_rec, last_alpha);                            \
                     dL_dalpha = fmaf(1 - accum_alpha_rec, dL_daccum, dL_dalpha);                                      \
-                    if (any_dn) { /* backward.cu:392-397; the normal is not staged: rare path, read it from the record */ \
+                    if (ANY_DN) { /* backward.cu:392-397; the normal is not staged: rare path, read it from the record */ \
                         const float4 nn = rec[(size_t)__float_as_uint(cc.w) * GS2D_REC_F4 + 3];                       \
                         an0 = fmaf(last_alpha, ln0, (1.f - last_alpha) * an0); ln0 = nn.x;                            \
                         dL_dalpha = fmaf(nn.x - an0, dn0, dL_dalpha);                                                 \
@@ -855,7 +727,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                     /* each row reduces ITS splat into the splat's LDS accumulators */                                \
                     float tot;                                                                                        \
                     GS2D_EXP_BUTTERFLY                                                                                \
-                    if (any_dn) {                                                                                     \
+                    if (ANY_DN) {                                                                                     \
                         g[12] = d_w * dn0; g[13] = d_w * dn1; g[14] = d_w * dn2;                                      \
                         tot = reduce16_row(g, lane);                                                                  \
                     } else {                                                                                          \
@@ -864,8 +736,8 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                     }                                                                                                 \
                     tot = __uint_as_float(__float_as_uint(tot) ^ slot_sign);                                          \
                     /* LDS float atomics run at a few lanes per clock: rows/components that sum to +-0 skip them */    \
-                    if (acc_comp >= 0 && tot != 0.f) GS2D_EXP_LDSADD(&wb.acc[(j & 63) * GS2D_ACC + acc_comp], tot);   \
-                    else if (any_dn && tot != 0.f)                                                                    \
+                    if (acc_comp >= 0 && tot != 0.f) GS2D_EXP_LDSADD(&wb.acc[(J & 63) * GS2D_ACC + acc_comp], tot);   \
+                    else if (ANY_DN && tot != 0.f)                                                                    \
                         atomicAdd(grad_rec + (size_t)__float_as_uint(cc.w) * GS2D_GRAD_FLOATS + (slot - 9), tot);                                   \
                     if (__ballot(d_t != 0.f) != 0) {                                                                  \
                         const float g_mx = row_sum_to_lane15(d_t * d0);                                               \
@@ -877,22 +749,20 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                     }                                                                                                 \
                 }                                                                                                     \
             }                                                                                                         \
-            if (!more) break;                                                                                         \
-            j = jn;                                                                                                   \
+            J = jnn;                                                                                                  \
+            if (++t >= trips) break;                                                                                  \
         }
         for (;;) {
-            GS2D_BWD_STEP(ga0, ga1, ga2, gap, gb0, gb1, gb2, gbp)
-            GS2D_BWD_STEP(gb0, gb1, gb2, gbp, ga0, ga1, ga2, gap)
+            GS2D_BWD_STEP(ga0, ga1, ga2, gap, j, gb0, gb1, gb2, gbp, jx)
+            GS2D_BWD_STEP(gb0, gb1, gb2, gbp, jx, ga0, ga1, ga2, gap, j)
         }
 #undef GS2D_BWD_STEP
         // flush: every touched splat of the batch goes to its global record once, four splats (one per row) per pass
         // two passes (eight splats) per iteration so the LDS round trips of one pass hide behind the other
-        uint64_t touched = fill == 64 ? ~0ull : (~0ull << (64 - fill));  // the staged slots
         const int flush_off = li < 3 ? li : (li < 12 ? li + 3 : 15);  // accumulator li -> offset in the gradient record
         const bool flush_lane = li < GS2D_ACC;
-        while (GS2D_EXP_FLUSH(touched)) {
-            const int fa = row_select(row8, pop_front(touched), pop_front(touched), pop_front(touched), pop_front(touched));
-            const int fb = row_select(row8, pop_front(touched), pop_front(touched), pop_front(touched), pop_front(touched));
+        for (int f0 = 64 - fill; GS2D_EXP_FLUSH(f0 < 64); f0 += 8) {
+            const int fa = f0 + row, fb = f0 + 4 + row;  // slots >= 64 do not exist
             float* pa = &wb.acc[(fa & 63) * GS2D_ACC + (flush_lane ? li : 0)];
             float* pb = &wb.acc[(fb & 63) * GS2D_ACC + (flush_lane ? li : 0)];
             const float va = *pa, vb = *pb;
@@ -907,6 +777,8 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
             }
         }
     }
+    };
+    if (any_dn) run(std::true_type{}); else run(std::false_type{});
     GS2D_PROF_END(1)
 }
 
@@ -915,7 +787,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
 namespace gs2d {
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
-                      const float* bg, float* out_color, float* out_others, float* pix_state, uint8_t* hits, int use_sa,
+                      const float* bg, float* out_color, float* out_others, float* pix_state, const uint8_t* hits, int use_sa,
                       hipStream_t s)
 {
     const int gx = (W + GS2D_TILE - 1) / GS2D_TILE, gy = (H + GS2D_TILE - 1) / GS2D_TILE;

@@ -193,9 +193,9 @@ void gs2d_binning_layout(int R, size_t offsets[2]);
 void gs2d_image_layout(int width, int height, size_t offsets[2]);
 
 /* Optional per-stage device timing with hipEvents recorded on the launch stream (bench.py's roofline leg).
- * ms[8] = preprocess, scan, duplicate, sort, ranges, blend_fwd, blend_bwd, preprocess_bwd; -1 = not recorded. */
+ * ms[9] = preprocess, scan, duplicate, sort, ranges, blend_fwd, blend_bwd, preprocess_bwd, cull; -1 = not recorded. */
 void gs2d_stage_timing_enable(int on);
-int gs2d_stage_timing_read(float ms[8]);
+int gs2d_stage_timing_read(float ms[9]);
 
 const char* gs2d_last_error(void);
 const char* gs2d_build_info(void);

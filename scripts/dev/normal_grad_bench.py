@@ -14,7 +14,7 @@ for chans in ((0, 1, 5, 6), (0, 1, 2, 3, 4, 5, 6)):
     dcolor, dallmap = [t.to(dev) for t in make_upstream_grads(W, H, seed=1, channels=chans)]
     L.gs2d_stage_timing_enable(1)
     acc = [0.0] * 8
-    buf = (C.c_float * 8)()
+    buf = (C.c_float * 9)()
     for it in range(13):
         for p in params.values(): p.grad = None
         m2 = torch.zeros_like(params["means3D"], requires_grad=True)

@@ -27,7 +27,9 @@ for k, name in ((0, "fwd"), (1, "bwd")):
     buf = np.zeros(ntiles * 4 * 4, np.uint64)
     assert L.gs2d_debug_read_wave_profile(k, buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size)) == 0
     a = buf.reshape(ntiles * 4, 4)
-    t0, t1, trips, hw = a[:, 0].astype(np.int64), a[:, 1].astype(np.int64), a[:, 2].astype(np.int64), a[:, 3]
+    t0, t1, hw = a[:, 0].astype(np.int64), a[:, 1].astype(np.int64), a[:, 3]
+    trips = (a[:, 2] & np.uint64(0xffffffff)).astype(np.int64)
+    stage_cyc = (a[:, 2] >> np.uint64(32)).astype(np.int64)  # shader cycles spent staging batches (s_memtime)
     out[name] = a
     start = t0.min()
     span = (t1.max() - start) / 100.0  # wall_clock64 ticks at 100 MHz -> us
@@ -52,6 +54,7 @@ for k, name in ((0, "fwd"), (1, "bwd")):
     edges = np.linspace(0, span, 11)
     alive = [(((t0 - start) / 100.0 < e1) & (end > e0)).sum() for e0, e1 in zip(edges[:-1], edges[1:])]
     print("   waves alive per decile:", alive)
+    print(f"   staging: mean {stage_cyc.mean():.0f} shader cycles per wave = {stage_cyc.mean() / 2.1e3:.1f} us at 2.1 GHz = {stage_cyc.sum() / 2.1e3 / dur.sum() * 100:.1f} % of wave time")
     print(f"   corr(trips, duration) {np.corrcoef(trips, dur)[0, 1]:.3f}; ns per trip (sum dur / sum trips) {dur.sum() / trips.sum() * 1e3:.1f}")
 os.makedirs("gpurun_out", exist_ok=True)
 np.savez_compressed("gpurun_out/wave_profile.npz", **out)
