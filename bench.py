@@ -5,11 +5,19 @@ One "step" = one forward + backward of the operator (GaussianRasterizer surface)
 GPU, 640x480, 500k Gaussians, inputs resident in HBM; with --gpus N > 1 each rank renders its own keyframe of the
 same replicated map and the [P,13] Gaussian-gradient bucket is all-reduced over RCCL (keyframe-sharded BA step,
 gaus_slam_amd/ba_shard.py).  Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     -- dominant kernel: algorithmic bytes / hipEvent-measured launch duration vs 8 TB/s HBM
-  cpu_baseline -- the CPU oracle (oracle/, C + OpenMP) timed on this box's host cores on the same workload.
+  roofline     -- dominant kernel: algorithmic bytes / hipEvent-measured launch duration vs 8 TB/s HBM, the HBM bytes
+                  of the committed rocprofv3 PMC profile, and the vector-issue ceiling the kernel actually runs against
+  cpu_baseline -- the CPU oracle (oracle/, C + OpenMP) timed on this box's host cores on the same workload, and the
+                  pure-PyTorch CPU render (oracle/torch_batched.py) fwd+bwd at 640x480 / 50k Gaussians.
+
+--workload selects the other configurations of BASELINE.md / BASELINE.json (same JSON shape, metric named after the
+workload): replica (1200x680 / 600k), scannetpp (1168x876 / 2M), scannetpp_ref (876x584 / 2M, the reference config's
+render size), b200k (640x480 / 200k), tracking (BASELINE.json configs[2]: one Frontend tracking iteration = fused
+pose-gradient render + tracking loss + Adam on the pose) and mapping (render + mapping loss + backward + fused Adam).
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -25,7 +33,17 @@ from gaus_slam_amd import _lib, ba_shard, render as gs_render  # noqa: E402
 from gaus_slam_amd.scene_synth import make_scene, make_upstream_grads, random_w2c, setup_camera  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+# Vector-issue ceiling, measured (profiles/issue_bench_r02.txt, profiles/select_bench_r02.txt): with 5-8 waves per SIMD a
+# SIMD retires one wave64 v_fma_f32 every 1.15-1.24 ns (2.4-2.9 cycles at the 2.0-2.4 GHz the chip holds under this load;
+# the guide's "2 cycles" row), v_cmp / v_min / v_max / v_cndmask ~1.75-1.9 ns, v_exp / v_rcp ~3.4 ns.
+# The ceiling below prices every instruction as an FMA (optimistic): 1024 SIMDs / 1.19 ns.
+VALU_PEAK_GINST = 1024 / 1.19
 STAGES = ["preprocess", "scan", "duplicate", "sort", "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "cull"]
+WORKLOADS = {  # name -> (W, H, P, regime)
+    "op": (640, 480, 500000, "mapping"), "b200k": (640, 480, 200000, "mapping"), "replica": (1200, 680, 600000, "tracking"),
+    "scannetpp": (1168, 876, 2000000, "mapping"), "scannetpp_ref": (876, 584, 2000000, "mapping"),
+    "tracking": (640, 480, 500000, "tracking"), "mapping": (640, 480, 500000, "mapping"),
+}
 
 
 def stage_bytes(P, R, HW):
@@ -43,14 +61,24 @@ def stage_bytes(P, R, HW):
     }
 
 
+def latest_profile(stem):
+    """Newest committed profiles/<stem>_rNN.json (falls back to the round-1 name)."""
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", stem + "_r[0-9][0-9].json")))
+    if c:
+        return c[-1]
+    p = os.path.join(ROOT, "profiles", stem + ".json")
+    return p if os.path.exists(p) else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--gaussians", type=int, default=500000)
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--workload", default="op", choices=sorted(WORKLOADS))
+    ap.add_argument("--gaussians", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--no-sa", action="store_true", help="use_sa=False (SLAM default is True)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--adam", nargs="?", const="fused", default=None, choices=["fused", "torch"],
@@ -62,6 +90,7 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--keyframes-per-gpu", type=int, default=1, help="keyframes each rank renders per step (default 1 = the "
                     "headline metric; >1 uses two HIP streams per rank, see ba_shard.KeyframeShardedBA)")
+    ap.add_argument("--json-out", default=None, help="also write the JSON line to this file (profiles/...)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -89,9 +118,49 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    P, W, H = args.gaussians, args.width, args.height
+    W0, H0, P0, regime = WORKLOADS[args.workload]
+    P, W, H = args.gaussians or P0, args.width or W0, args.height or H0
     use_sa = not args.no_sa
-    sc = make_scene(P, W, H, seed=0, regime="mapping")
+    if args.workload in ("tracking", "mapping"):
+        result = slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world)
+    else:
+        result = op_workload(args, dev, P, W, H, regime, use_sa, rank, world)
+    if rank == 0 and result is not None:
+        line = json.dumps(result)
+        print(line, flush=True)
+        if args.json_out:
+            os.makedirs(os.path.dirname(os.path.abspath(args.json_out)), exist_ok=True)
+            with open(args.json_out, "w") as f:
+                f.write(line + "\n")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+def timed(one_step, steps, warmup, world, dev):
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        one_step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
+    sc = make_scene(P, W, H, seed=0, regime=regime)
     cam = sc["cam"]
     if rank > 0:  # every rank renders its own keyframe: a different small SE3 around the same map
         import numpy as np
@@ -144,129 +213,181 @@ def main():
                 ba.bucket.pack(g)
             opt.step(ba.bucket.flat)
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one_step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(one_step, args.steps, args.warmup, world, dev)
     frames = args.steps * world * kpg
     ms_per_step = elapsed / args.steps * 1e3
-
-    result = None
-    if rank == 0:
-        L = _lib.lib()
-        # ---- per-stage device time via hipEvents on the launch stream (separate, untimed leg)
-        L.gs2d_stage_timing_enable(1)
-        acc = [0.0] * len(STAGES)
-        nrep = 10
-        buf = (C.c_float * len(STAGES))()
-        for _ in range(nrep):
-            ba.local_backward(0)
-            L.gs2d_stage_timing_read(buf)
-            for i in range(len(STAGES)):
-                acc[i] += max(buf[i], 0.0)
-        L.gs2d_stage_timing_enable(0)
-        stage_ms = {n: acc[i] / nrep for i, n in enumerate(STAGES)}
-        visible = int((last["radius"] > 0).sum().item())
-        from gaus_slam_amd import rasterizer
-        with torch.no_grad():
-            e = torch.empty(0, device=dev)
-            R = rasterizer.rasterize_gaussians(settings.bg, params["means3D"], params["colors"], params["opacities"],
-                                               params["scales"], params["rotations"], 1.0, e, settings.viewmatrix,
-                                               settings.projmatrix, settings.tanfovx, settings.tanfovy, H, W, e, 0,
-                                               settings.campos, use_sa, False, False)[0]
-        sb = stage_bytes(P, R, H * W)
-        dom = max(("blend_fwd", "blend_bwd", "sort", "preprocess", "preprocess_bwd"), key=lambda n: stage_ms[n])
-        achieved = sb[dom] / (stage_ms[dom] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom)
-            except Exception:
-                traffic = None
-        # measured streaming bandwidth of this box (1 GiB device-to-device copy), quoted beside the 8 TB/s spec peak
-        x = torch.empty(1 << 28, dtype=torch.float32, device=dev)
-        y = torch.empty_like(x)
-        for _ in range(2):
-            y.copy_(x)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            y.copy_(x)
-        e1.record()
+    allreduce_ms = None
+    if world > 1:  # the collective alone, on the same bucket (reported separately)
         torch.cuda.synchronize()
-        copy_gbs = 5 * 2 * x.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del x, y
-        # secondary (honest) ceiling: the dominant kernel is VALU-issue bound; instruction counts come from the committed
-        # rocprofv3 PMC summary, the 4-cycles-per-wave64-fp32-instruction peak from scripts/dev/valu_bench.hip
-        valu = None
-        vpath = os.path.join(ROOT, "profiles", "pmc_valu.json")
-        if os.path.exists(vpath) and (P, W, H) == (500000, 640, 480):
-            try:
-                vi = json.load(open(vpath)).get(dom)
-                peak_ginst = 1024 * 2.4 / 4.0  # G wave-instructions/s
-                ach = vi["valu_wave_insts"] / (stage_ms[dom] * 1e-3) / 1e9
-                valu = {"kernel": dom, "achieved_Gwaveinst_s": round(ach, 1), "peak_Gwaveinst_s": peak_ginst,
-                        "frac": round(ach / peak_ginst, 3)}
-            except Exception:
-                valu = None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "measured_copy_GBps": round(copy_gbs, 1), "valu_ceiling": valu,
-                    "kernel_ms": round(stage_ms[dom], 4),
-                    "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-                    "frame_algorithmic_bytes": 492 * P + 196 * R + 136 * H * W,
-                    "frame_frac_of_hbm_peak": round((492 * P + 196 * R + 136 * H * W) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-        cpu_baseline = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu_baseline = cpu_baseline_leg(sc, W, H, use_sa)
-        result = {
-            "metric": "fwd+bwd frames/sec @ 640x480, 500k Gaussians", "value": round(frames / elapsed, 3),
-            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic {W}x{H} / {P} Gaussians (BASELINE.md config B), mapping regime, "
-                                   f"use_sa={use_sa}, {kpg} keyframe{'s' if kpg > 1 else ''} per GPU" + (" on two HIP streams" if kpg > 1 else ""), "num_rendered": R, "visible": visible,
-                       "step": "op forward+backward" + (" + all-reduce of the [P,13] grad bucket" if world > 1 else "")
-                               + (f" + {args.adam} Adam (lr=0)" if args.adam else ""),
-                       "parallelism": f"keyframe-sharded x{world}"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
-        }
-        print(json.dumps(result), flush=True)
-    if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
-    return result
+        t0 = time.perf_counter()
+        for _ in range(10):
+            ba.bucket.all_reduce()
+        torch.cuda.synchronize()
+        allreduce_ms = (time.perf_counter() - t0) / 10 * 1e3
+    if rank != 0:
+        return None
+
+    L = _lib.lib()
+    # ---- per-stage device time via hipEvents on the launch stream (separate, untimed leg)
+    L.gs2d_stage_timing_enable(1)
+    acc = [0.0] * len(STAGES)
+    nrep = 10
+    buf = (C.c_float * len(STAGES))()
+    for _ in range(nrep):
+        ba.local_backward(0)
+        L.gs2d_stage_timing_read(buf)
+        for i in range(len(STAGES)):
+            acc[i] += max(buf[i], 0.0)
+    L.gs2d_stage_timing_enable(0)
+    stage_ms = {n: acc[i] / nrep for i, n in enumerate(STAGES)}
+    visible = int((last["radius"] > 0).sum().item())
+    from gaus_slam_amd import rasterizer
+    with torch.no_grad():
+        e = torch.empty(0, device=dev)
+        R = rasterizer.rasterize_gaussians(settings.bg, params["means3D"], params["colors"], params["opacities"],
+                                           params["scales"], params["rotations"], 1.0, e, settings.viewmatrix,
+                                           settings.projmatrix, settings.tanfovx, settings.tanfovy, H, W, e, 0,
+                                           settings.campos, use_sa, False, False)[0]
+    sb = stage_bytes(P, R, H * W)
+    dom = max(("blend_fwd", "blend_bwd", "sort", "cull", "preprocess", "preprocess_bwd"), key=lambda n: stage_ms[n])
+    achieved = sb[dom] / (stage_ms[dom] * 1e-3) / 1e9
+    headline = (P, W, H) == (500000, 640, 480)
+    traffic, traffic_source = None, None
+    tpath = latest_profile("pmc_traffic")
+    if tpath and headline:
+        try:
+            traffic = json.load(open(tpath)).get(dom)
+            traffic_source = (f"{os.path.relpath(tpath, ROOT)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                              "committed with the kernels; not measured in this run")
+        except Exception:
+            traffic = None
+    # measured streaming bandwidth of this box (1 GiB device-to-device copy), quoted beside the 8 TB/s spec peak
+    x = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    for _ in range(2):
+        y.copy_(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        y.copy_(x)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * x.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del x, y
+    # The ceiling the dominant kernel actually runs against: vector-instruction issue.  Instruction counts come from the
+    # committed rocprofv3 PMC profile of this command, the peak from the kept microbenchmark output (see VALU_PEAK_GINST).
+    valu = None
+    vpath = latest_profile("pmc_valu")
+    if vpath and headline:
+        try:
+            vi = json.load(open(vpath)).get(dom)
+            ach = vi["valu_wave_insts"] / (stage_ms[dom] * 1e-3) / 1e9
+            valu = {"kernel": dom, "achieved_Gwaveinst_s": round(ach, 1), "peak_Gwaveinst_s": round(VALU_PEAK_GINST, 1),
+                    "frac": round(ach / VALU_PEAK_GINST, 3), "valu_wave_insts": vi["valu_wave_insts"],
+                    "salu_wave_insts": vi.get("salu_wave_insts"),
+                    "source": f"{os.path.relpath(vpath, ROOT)} (SQ_INSTS_VALU of the committed PMC profile); peak from "
+                              "profiles/issue_bench_r02.txt, profiles/select_bench_r02.txt"}
+        except Exception:
+            valu = None
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                "closest_ceiling": "valu-issue" if valu and valu["frac"] > achieved / HBM_PEAK_GBS else "hbm",
+                "measured_copy_GBps": round(copy_gbs, 1), "valu_ceiling": valu,
+                "kernel_ms": round(stage_ms[dom], 4),
+                "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+                "frame_algorithmic_bytes": 492 * P + 196 * R + 136 * H * W,
+                "frame_frac_of_hbm_peak": round((492 * P + 196 * R + 136 * H * W) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    cpu_baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = cpu_baseline_leg(sc, W, H, use_sa)
+    return {
+        "metric": f"fwd+bwd frames/sec @ {W}x{H}, {P // 1000}k Gaussians", "value": round(frames / elapsed, 3),
+        "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"synthetic {W}x{H} / {P} Gaussians ({args.workload}; BASELINE.md section 2), {regime} regime, "
+                               f"use_sa={use_sa}, {kpg} keyframe{'s' if kpg > 1 else ''} per GPU" + (" on two HIP streams" if kpg > 1 else ""), "num_rendered": R, "visible": visible,
+                   "step": "op forward+backward" + (" + all-reduce of the [P,13] grad bucket" if world > 1 else "")
+                           + (f" + {args.adam} Adam (lr=0)" if args.adam else ""),
+                   "parallelism": f"keyframe-sharded x{world}", "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4)},
+        "roofline": roofline, "cpu_baseline": cpu_baseline,
+    }
+
+
+def slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world):
+    """BASELINE.json configs[2] (tracking) / the backend mapping step: whole SLAM iterations around the operator, in the
+    fused formulation this package offers (gaus_slam_amd/tracking.py, loss.py, optim.py)."""
+    import numpy as np
+    from gaus_slam_amd import loss as gl, optim as gs_optim, tracking
+    if world > 1:
+        raise SystemExit("the tracking / mapping workloads are single-GPU iterations")
+    names = ("means3D", "opacities", "scales", "rotations", "colors")
+    g = torch.Generator().manual_seed(0)
+    gt_color = torch.rand(H, W, 3, generator=g).to(dev)
+    gt_depth = (0.5 + 5 * torch.rand(H, W, 1, generator=g)).to(dev)
+    if args.workload == "tracking":
+        sc = make_scene(P, W, H, seed=0, regime="tracking")
+        settings = gs_render.settings_from_camera(sc["cam"], dev, use_sa=use_sa)
+        p = {k: sc[k].to(dev) for k in names}
+        w2c = random_w2c(np.random.default_rng(1), 2.0, 0.05).to(dev).requires_grad_(True)
+        opt = torch.optim.Adam([w2c], lr=0.0)  # lr = 0: the pose (and so the workload) stays fixed, the update runs
+
+        def one_step():
+            opt.zero_grad(set_to_none=True)
+            pkg = tracking.render_tracking(settings, w2c, p["means3D"], p["opacities"], p["colors"], p["scales"], p["rotations"])
+            gl.tracking_loss(pkg["render_color"], pkg["allmap"], gt_color, gt_depth, 0.5, 1.0).backward()
+            opt.step()
+        step_desc = "pose transform fused into the preprocess + render + fused tracking loss + pose-only backward + Adam on the pose"
+        metric = f"tracking iterations/sec @ {W}x{H}, {P // 1000}k Gaussians"
+    else:
+        sc = make_scene(P, W, H, seed=0, regime="mapping")
+        settings = gs_render.settings_from_camera(sc["cam"], dev, use_sa=use_sa)
+        soa = gs_optim.GaussianSoA({k: sc[k].to(dev) for k in names})
+        leaves = dict(soa.leaves())
+        fopt = gs_optim.FusedGaussianAdam(soa, {})
+
+        def rasterize(q):
+            m2 = torch.zeros_like(q["means3D"], requires_grad=True)
+            return gs_render.render(settings, q["means3D"], m2, q["opacities"], colors_precomp=q["colors"], scales=q["scales"],
+                                    rotations=q["rotations"])
+
+        def loss_fn(q, _kf):
+            pk = rasterize(q)
+            return gl.mapping_loss(pk["render_color"], pk["allmap"], gt_color, gt_depth, 0.5, 1.0, 0.1)
+        ba = ba_shard.KeyframeShardedBA(leaves, loss_fn, direct_grads=True)
+
+        def one_step():
+            ba.step([0])
+            fopt.step(ba.bucket.flat, leaves)
+        step_desc = "render + fused mapping loss + backward (gradients written into the bucket) + fused Adam over the SoA"
+        metric = f"mapping iterations/sec @ {W}x{H}, {P // 1000}k Gaussians"
+    elapsed = timed(one_step, args.steps, args.warmup, world, dev)
+    return {"metric": metric, "value": round(args.steps / elapsed, 3), "unit": "iterations/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic {W}x{H} / {P} Gaussians, {args.workload} iteration (BASELINE.json configs[2] loop shape), "
+                                   f"use_sa={use_sa}", "step": step_desc, "parallelism": "single GPU"},
+            "roofline": None, "cpu_baseline": None}
 
 
 def cpu_baseline_leg(sc, W, H, use_sa):
-    """The CPU oracle (C, OpenMP over tiles) on the same scene: 1 warm-up + 2 timed fwd+bwd frames."""
+    """(1) The CPU oracle (C, OpenMP over tiles) on the same scene: 1 warm-up + 2 timed fwd+bwd frames -> `value`.
+    (2) The pure-PyTorch CPU render (oracle/torch_batched.py, all host threads): BASELINE.md section 4's cases, bounded
+    so that the default run stays within minutes."""
     from oracle import gs2d_oracle as orc
     cores = os.cpu_count() or 1
     orc.set_threads(cores)
     cam = sc["cam"]
     dc, da = make_upstream_grads(W, H, seed=1)
-    dc, da = dc.numpy(), da.numpy()
+    dcn, dan = dc.numpy(), da.numpy()
 
     def frame():
         st = orc.forward(sc["means3D"].numpy(), sc["opacities"].numpy(), cam.viewmatrix.numpy(), cam.projmatrix.numpy(),
                          cam.campos.numpy(), W, H, cam.tanfovx, cam.tanfovy, scales=sc["scales"].numpy(),
                          rotations=sc["rotations"].numpy(), colors_precomp=sc["colors"].numpy(), use_sa=use_sa,
                          want_stability=False)
-        orc.backward(st, dc, da)
+        orc.backward(st, dcn, dan)
 
     frame()
     reps = 2
@@ -274,24 +395,50 @@ def cpu_baseline_leg(sc, W, H, use_sa):
     for _ in range(reps):
         frame()
     dt = (time.perf_counter() - t0) / reps
-    # BASELINE.json configs[0]: 160x120 / 256 Gaussians forward through the pure-PyTorch CPU path (oracle/torch_ref.py)
-    torch_a = None
-    try:
-        from oracle import torch_ref
-        sa = make_scene(256, 160, 120, seed=0, regime="mapping")
-        ca = sa["cam"]
-        torch.set_num_threads(min(cores, 8))  # thousands of tiny ops: more threads only add synchronisation cost
-        t1 = time.perf_counter()
-        with torch.no_grad():
-            torch_ref.render(sa["means3D"], sa["scales"], sa["rotations"], sa["opacities"], sa["colors"], ca.viewmatrix,
-                             ca.projmatrix, 160, 120, use_sa=use_sa)
-        torch_a = round(time.perf_counter() - t1, 4)
-    except Exception as ex:  # the CPU reference is optional colour, never a reason to fail the bench
-        torch_a = f"failed: {ex}"
+    torch_leg = pure_pytorch_leg(W, H, use_sa, cores)
     return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "pure_pytorch_cpu_160x120_256_fwd_s": torch_a, "pure_pytorch_threads": min(cores, 8),
             "sample": f"same workload ({W}x{H}, {sc['means3D'].shape[0]} Gaussians), oracle/gs2d_oracle.c fwd+bwd, "
-                      f"OpenMP over tiles in the blend stages, 1 warm-up + {reps} timed frames"}
+                      f"OpenMP over tiles in the blend stages, 1 warm-up + {reps} timed frames",
+            "pure_pytorch": torch_leg}
+
+
+def pure_pytorch_leg(W, H, use_sa, cores):
+    """oracle/torch_batched.py on the host cores: BASELINE.json configs[0] (160x120 / 256, forward and fwd+bwd), 640x480 /
+    50k fwd+bwd (autograd), and 640x480 / 500k forward on a bounded number of list positions scaled to the full frame."""
+    threads = min(cores, 64)  # [tiles, 256] elementwise ops: more threads than that only add synchronisation cost
+    out = {"threads": threads, "renderer": "oracle/torch_batched.py (all tiles in lock-step, torch.autograd backward)"}
+    try:
+        from oracle import torch_batched
+        torch.set_num_threads(threads)
+
+        def run(P, w, h, grad, max_steps=None):
+            s = make_scene(P, w, h, seed=0, regime="mapping")
+            c = s["cam"]
+            leaves = {k: (s[k].clone().requires_grad_(True) if grad else s[k]) for k in ("means3D", "scales", "rotations", "opacities", "colors")}
+            dc, da = make_upstream_grads(w, h, seed=1)
+            t0 = time.perf_counter()
+            with torch.enable_grad() if grad else torch.no_grad():
+                r = torch_batched.render(leaves["means3D"], leaves["scales"], leaves["rotations"], leaves["opacities"],
+                                         leaves["colors"], c.viewmatrix, c.projmatrix, w, h, use_sa=use_sa, max_steps=max_steps)
+                t1 = time.perf_counter()
+                if grad:
+                    ((r["color"] * dc).sum() + (r["allmap"] * da).sum()).backward()
+            return t1 - t0, time.perf_counter() - t0, r["steps"], r["steps_run"]
+
+        run(256, 160, 120, False)  # warm-up (thread pool, allocator)
+        f, _, _, _ = run(256, 160, 120, False)
+        _, fb, _, _ = run(256, 160, 120, True)
+        out["160x120_256_fwd_s"], out["160x120_256_fwd_bwd_s"] = round(f, 4), round(fb, 4)
+        f, fb, steps, _ = run(50000, 640, 480, True)
+        out["640x480_50k_fwd_bwd_s"], out["640x480_50k_fwd_s_with_autograd_tape"], out["640x480_50k_list_steps"] = round(fb, 3), round(f, 3), steps
+        out["640x480_50k_fwd_bwd_frames_per_s"] = round(1.0 / fb, 4)
+        f, _, steps, ran = run(500000, 640, 480, False, max_steps=150)
+        out["640x480_500k_fwd_s_scaled"] = round(f * steps / max(ran, 1), 2)
+        out["640x480_500k_note"] = (f"forward only, {ran} of {steps} list positions timed ({round(f, 2)} s) and scaled; fwd+bwd by autograd "
+                                    "would need ~10x the 50k run's 14 GB tape")
+    except Exception as ex:  # the CPU reference is context, never a reason to fail the bench
+        out["error"] = f"{type(ex).__name__}: {ex}"
+    return out
 
 
 if __name__ == "__main__":

@@ -10,7 +10,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 EXPORTS = ["gs2d_forward", "gs2d_backward", "gs2d_forward_posed", "gs2d_backward_posed", "gs2d_mark_visible", "sknn_dist2", "gs2d_geometry_bytes",
            "gs2d_image_bytes", "gs2d_binning_bytes", "gs2d_geometry_layout", "gs2d_binning_layout",
            "gs2d_image_layout", "gs2d_last_error", "gs2d_build_info", "gs2d_stage_timing_enable",
-           "gs2d_stage_timing_read", "gs2d_slam_loss", "gs2d_adam_step", "gs2d_pose_quat"]
+           "gs2d_stage_timing_read", "gs2d_slam_loss", "gs2d_adam_step", "gs2d_pose_quat", "gs2d_backward_staged"]
 
 _lib = None
 
@@ -39,6 +39,8 @@ def lib():
     L.gs2d_forward_posed.argtypes = L.gs2d_forward.argtypes[:-1] + [vp, vp, vp]
     L.gs2d_backward_posed.restype = i
     L.gs2d_backward_posed.argtypes = L.gs2d_backward.argtypes[:-1] + [vp, vp, vp, vp]
+    L.gs2d_backward_staged.restype = i
+    L.gs2d_backward_staged.argtypes = [i, i, i] + L.gs2d_backward_posed.argtypes
     L.gs2d_pose_quat.restype = i
     L.gs2d_pose_quat.argtypes = [vp, vp, vp]
     L.gs2d_mark_visible.restype = i

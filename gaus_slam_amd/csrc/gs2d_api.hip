@@ -8,6 +8,10 @@
 #include <string.h>
 #include <chrono>
 #include <string>
+#include <thread>
+#if defined(__x86_64__) || defined(__i386__)
+#include <immintrin.h>
+#endif
 
 namespace {
 
@@ -84,7 +88,21 @@ struct PinnedWord {
     ~PinnedWord() { if (p) (void)hipHostFree(p); }
 };
 thread_local PinnedWord g_pinned;
-thread_local uint32_t g_last_R = 0;  // previous forward's num_rendered: sizes the early binning allocation
+// previous forward's num_rendered for the same problem shape: sizes the early binning allocation (a guess only: the
+// chunk is re-requested with the exact size when the guess was too small)
+struct LastCount { int P = -1, W = 0, H = 0; uint32_t R = 0; };
+thread_local LastCount g_last;
+
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    _mm_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
 
 }  // namespace
 
@@ -189,41 +207,47 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     // On a loaded host a blocking hipStreamSynchronize can cost milliseconds of scheduler latency per call; the poll
     // returns within a microsecond of the store landing.  Falls back to a real synchronise after ~2 s (surfacing any
     // GPU error).
-    if (!g_pinned.p) GS2D_CHECK(hipHostMalloc((void**)&g_pinned.p, 64, hipHostMallocDefault), "hipHostMalloc");
+    // coherent pinned memory: the device's system-scope store must become visible to the polling CPU without a sync
+    if (!g_pinned.p) GS2D_CHECK(hipHostMalloc((void**)&g_pinned.p, 64, hipHostMallocCoherent), "hipHostMalloc");
     volatile uint32_t* pinned = g_pinned.p;
     *pinned = 0xFFFFFFFFu;
     g_timer.begin(ST_SCAN, s);
     gs2d::launch_offsets_blocksums(P, scan_tmp, total_dev, g_pinned.p, s);
     g_timer.end(ST_SCAN, s);
-    GS2D_STAGE("scan");
-
-    // While the GPU works towards num_rendered, ask for the binning chunk already, sized from the previous call's count
-    // (+12.5 %): the allocator callback (a trip through the caller's runtime) then costs nothing on the critical
-    // path.  If the guess turns out too small the callback is simply invoked a second time with the exact size.
-    // (the image chunk is not needed before the tile ranges are written, so its allocator round trip also happens here)
-    char* img = (char*)image_alloc(image_user, IL.total);
-    if (!img) return fail_msg("image allocation failed");
-    const size_t guess_R = (size_t)g_last_R + g_last_R / 8 + 4096;
-    const size_t pre_bytes = bin_layout((int)(guess_R > 0x7fffffffull ? 0x7fffffffull : guess_R)).total;
-    char* bin_pre = (char*)binning_alloc(binning_user, pre_bytes);
     {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return fail("scan", le);  // nothing was enqueued: nothing will store into the word
+    }
+    // From here on the scan kernel WILL store into the pinned word, so every return path first waits for that store
+    // (a later forward on this thread would otherwise reset the sentinel and could pick up this call's stale total).
+    auto wait_total = [&]() -> bool {
         const auto t0 = std::chrono::steady_clock::now();
         uint64_t spins = 0;
         while (*pinned == 0xFFFFFFFFu) {
-            __builtin_ia32_pause();
-            if ((++spins & 0xFFFFu) == 0 &&
-                std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
-                GS2D_CHECK(hipStreamSynchronize(s), "sync num_rendered");
-                break;
-            }
+            cpu_relax();
+            if ((++spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2))
+                return hipStreamSynchronize(s) == hipSuccess && *pinned != 0xFFFFFFFFu;
         }
-    }
+        return true;
+    };
+    // While the GPU works towards num_rendered, ask for the image chunk and already for the binning chunk, sized from the
+    // previous call's count for this problem shape (+12.5 %): the allocator callbacks (trips through the caller's runtime)
+    // then cost nothing on the critical path.  If the guess turns out too small the callback is simply invoked a second
+    // time with the exact size.
+    char* img = (char*)image_alloc(image_user, IL.total);
+    if (!img) { (void)wait_total(); return fail_msg("image allocation failed"); }
+    const bool same_shape = g_last.P == P && g_last.W == width && g_last.H == height;
+    const size_t guess_R = same_shape ? (size_t)g_last.R + g_last.R / 8 + 4096 : (size_t)P * 3 + 4096;
+    const size_t pre_bytes = bin_layout((int)(guess_R > 0x7fffffffull ? 0x7fffffffull : guess_R)).total;
+    char* bin_pre = (char*)binning_alloc(binning_user, pre_bytes);
+    if (!wait_total()) return fail_msg("num_rendered read-back failed");
+    if (debug) GS2D_CHECK(hipStreamSynchronize(s), "scan");
     const uint32_t num_rendered_u = *pinned;
     if (num_rendered_u == 0xFFFFFFFFu) return fail_msg("num_rendered read-back failed");
     if (num_rendered_u > 0x7fffffffu) return fail_msg("num_rendered overflows int32");
     const int R = (int)num_rendered_u;
 
-    g_last_R = num_rendered_u;
+    g_last.P = P; g_last.W = width; g_last.H = height; g_last.R = num_rendered_u;
     const BinLayout BL = bin_layout(R);  // offsets always follow the true count; the chunk may be larger than BL.total
     char* bin = (bin_pre && BL.total <= pre_bytes) ? bin_pre : (char*)binning_alloc(binning_user, BL.total);
     if (!bin) return fail_msg("binning allocation failed");
@@ -301,27 +325,30 @@ int gs2d_forward(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_alloc_f
                               out_color, out_others, radii, use_sa, debug, nullptr, nullptr, stream);
 }
 
-int gs2d_backward_posed(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
-                        const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                        const float* rotations, const float* transMat_precomp, const float* viewmatrix,
-                        const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
-                        char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix,
-                        const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor,
-                        float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot, int use_sa,
-                        int debug, const float* pose_Rt, const float* pose_quat, float* dL_dpose, void* stream)
+int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M, int R, const float* background, int width,
+                         int height, const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                         float scale_modifier, const float* rotations, const float* transMat_precomp, const float* viewmatrix,
+                         const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                         char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix,
+                         const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor,
+                         float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot, int use_sa,
+                         int debug, const float* pose_Rt, const float* pose_quat, float* dL_dpose, void* stream)
 {
+    if ((stages & ~3) != 0 || stages == 0) return fail_msg("stages must be a combination of GS2D_BWD_BLEND (1) and GS2D_BWD_PREPROCESS (2)");
     if ((pose_Rt == nullptr) != (pose_quat == nullptr)) return fail_msg("pose_Rt and pose_quat must be given together");
     if (pose_Rt != nullptr && dL_dpose == nullptr) return fail_msg("dL_dpose is required with a pose");
-    {   // pose-only call: all six per-Gaussian outputs NULL (needs a pose and no SH gradient), otherwise none of them
+    if ((stages & 2) != 0) {   // pose-only call: all six per-Gaussian outputs NULL (needs a pose and no SH gradient), otherwise none of them
         const int nulls = !dL_dmean2D + !dL_dopacity + !dL_dcolor + !dL_dmean3D + !dL_dscale + !dL_drot;
         if (nulls != 0 && (nulls != 6 || pose_Rt == nullptr || shs != nullptr))
             return fail_msg("per-Gaussian gradient outputs may only be omitted all together, with a pose and without SH");
     }
-    if (dL_dpose != nullptr)
-        GS2D_CHECK(hipMemsetAsync(dL_dpose, 0, sizeof(float) * 12, (hipStream_t)stream), "memset dL_dpose");
     (void)colors_precomp; (void)transMat_precomp; (void)scale_modifier;
     hipStream_t s = (hipStream_t)stream;
+    // the pose gradient is accumulated by the preprocess stage(s): cleared once, by the call that runs the blend stage
+    if (dL_dpose != nullptr && (stages & 1) != 0)
+        GS2D_CHECK(hipMemsetAsync(dL_dpose, 0, sizeof(float) * 12, s), "memset dL_dpose");
     if (P <= 0) return 0;
+    if (g_begin < 0 || g_end > P || g_begin > g_end) return fail_msg("bad Gaussian range");
     if (!geom_buffer || !img_buffer || (R > 0 && !binning_buffer)) return fail_msg("missing forward state");
     const GeomLayout GL = geom_layout(P);
     const BinLayout BL = bin_layout(R);
@@ -334,30 +361,50 @@ int gs2d_backward_posed(int P, int D, int M, int R, const float* background, int
     const uint2* ranges = (const uint2*)(img_buffer + IL.ranges);
     const float* pix_state = (const float*)(img_buffer + IL.pix);
 
-    GS2D_CHECK(hipMemsetAsync(grad_rec, 0, sizeof(float) * GS2D_GRAD_FLOATS * (size_t)P, s), "memset grad_rec");
-    if (R > 0) {
-        g_timer.begin(ST_BLEND_BWD, s);
-        gs2d::launch_blend_bwd(width, height, ranges, point_list, rec, background, pix_state, hits, dL_dpix, dL_depths,
-                               grad_rec, use_sa, s);
-        g_timer.end(ST_BLEND_BWD, s);
-        GS2D_STAGE("blend_bwd");
+    if ((stages & 1) != 0) {
+        GS2D_CHECK(hipMemsetAsync(grad_rec, 0, sizeof(float) * GS2D_GRAD_FLOATS * (size_t)P, s), "memset grad_rec");
+        if (R > 0) {
+            g_timer.begin(ST_BLEND_BWD, s);
+            gs2d::launch_blend_bwd(width, height, ranges, point_list, rec, background, pix_state, hits, dL_dpix, dL_depths,
+                                   grad_rec, use_sa, s);
+            g_timer.end(ST_BLEND_BWD, s);
+            GS2D_STAGE("blend_bwd");
+        }
     }
-    // rasterizer_impl.cu:396-397 + backward.cu:641-642: the backward rebuilds W,H from focal*tan in float32
-    const float focal_y = height / (2.0f * tan_fovy);
-    const float focal_x = width / (2.0f * tan_fovx);
-    CamParams cam;
-    cam.vm = viewmatrix; cam.pm = projmatrix; cam.campos = campos;
-    cam.W = (int)(focal_x * tan_fovx * 2);
-    cam.H = (int)(focal_y * tan_fovy * 2);
-    cam.gx = (width + GS2D_TILE - 1) / GS2D_TILE;
-    cam.gy = (height + GS2D_TILE - 1) / GS2D_TILE;
-    g_timer.begin(ST_PREPROCESS_BWD, s);
-    gs2d::launch_preprocess_bwd(P, D, M, means3D, rec, radii, shs, clamped, scales, rotations, cam, grad_rec,
-                                dL_dtransMat, dL_dnormal, dL_dcolor, dL_dopacity, dL_dsh, dL_dmean2D, dL_dmean3D,
-                                dL_dscale, dL_drot, pose_Rt, pose_quat, pose_Rt ? dL_dpose : nullptr, s);
-    g_timer.end(ST_PREPROCESS_BWD, s);
-    GS2D_STAGE("preprocess_bwd");
+    if ((stages & 2) != 0 && g_end > g_begin) {
+        // rasterizer_impl.cu:396-397 + backward.cu:641-642: the backward rebuilds W,H from focal*tan in float32
+        const float focal_y = height / (2.0f * tan_fovy);
+        const float focal_x = width / (2.0f * tan_fovx);
+        CamParams cam;
+        cam.vm = viewmatrix; cam.pm = projmatrix; cam.campos = campos;
+        cam.W = (int)(focal_x * tan_fovx * 2);
+        cam.H = (int)(focal_y * tan_fovy * 2);
+        cam.gx = (width + GS2D_TILE - 1) / GS2D_TILE;
+        cam.gy = (height + GS2D_TILE - 1) / GS2D_TILE;
+        g_timer.begin(ST_PREPROCESS_BWD, s);
+        gs2d::launch_preprocess_bwd(g_begin, g_end, D, M, means3D, rec, radii, shs, clamped, scales, rotations, cam, grad_rec,
+                                    dL_dtransMat, dL_dnormal, dL_dcolor, dL_dopacity, dL_dsh, dL_dmean2D, dL_dmean3D,
+                                    dL_dscale, dL_drot, pose_Rt, pose_quat, pose_Rt ? dL_dpose : nullptr, s);
+        g_timer.end(ST_PREPROCESS_BWD, s);
+        GS2D_STAGE("preprocess_bwd");
+    }
     return 0;
+}
+
+int gs2d_backward_posed(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                        const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                        const float* rotations, const float* transMat_precomp, const float* viewmatrix,
+                        const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                        char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix,
+                        const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor,
+                        float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot, int use_sa,
+                        int debug, const float* pose_Rt, const float* pose_quat, float* dL_dpose, void* stream)
+{
+    return gs2d_backward_staged(3, 0, P > 0 ? P : 0, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales,
+                                scale_modifier, rotations, transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy,
+                                radii, geom_buffer, binning_buffer, img_buffer, dL_dpix, dL_depths, dL_dmean2D, dL_dnormal,
+                                dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot, use_sa, debug, pose_Rt,
+                                pose_quat, dL_dpose, stream);
 }
 
 int gs2d_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,

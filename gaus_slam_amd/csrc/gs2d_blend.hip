@@ -63,6 +63,9 @@ __device__ __forceinline__ void wave_lds_sync()
 #ifndef GS2D_WAVES_PER_EU
 #define GS2D_WAVES_PER_EU 5  // 96 VGPRs: all 1200 tiles of a 640x480 frame resident at once (5 workgroups per CU)
 #endif
+#ifndef GS2D_BWD_PREFETCH
+#define GS2D_BWD_PREFETCH 0  // cull bits + ids one chunk ahead in the backward: measured neutral to slightly negative (registers)
+#endif
 #ifndef GS2D_FWD_WAVES_PER_EU
 #define GS2D_FWD_WAVES_PER_EU GS2D_WAVES_PER_EU
 #endif
@@ -164,6 +167,36 @@ __device__ __forceinline__ int xcd_tile(int block, int ntiles)
     return tile < ntiles ? tile : -1;  // the last band may be short
 }
 
+// Issue priority from the share of the wave's list that is still ahead of it.  The SIMD arbiter serves the oldest wave
+// first, so without this the waves of a SIMD finish one after the other and the youngest runs its last third alone, at
+// single-wave issue rate and with every latency exposed (scripts/dev/wave_profile.py: the last 40 % of the kernel ran
+// with less than half of the waves).  Priority by remaining work makes the laggard the favourite: the waves of a SIMD
+// stay together and finish together.  Placement only -- results do not depend on it.
+#ifndef GS2D_PRIO_SHIFT
+#define GS2D_PRIO_SHIFT 1  // level boundaries at remaining = total >> (SHIFT * k), k = 1..3 (1: 1/2, 1/4, 1/8)
+#endif
+#ifndef GS2D_NO_SETPRIO
+__device__ __forceinline__ void prio_by_remaining(uint32_t remaining, uint32_t total)
+{
+    // Geometric level boundaries: only the END of the lists has to be synchronised (a spread early on costs nothing), and
+    // inside the last level the arbiter is back to oldest-first, so that level is kept short.
+#if GS2D_PRIO_SHIFT == 0
+    const uint32_t q = remaining * 4u;  // uniform quarters
+    if (q > total * 3u) __builtin_amdgcn_s_setprio(3);
+    else if (q > total * 2u) __builtin_amdgcn_s_setprio(2);
+    else if (q > total) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+#else
+    if (remaining > (total >> GS2D_PRIO_SHIFT)) __builtin_amdgcn_s_setprio(3);
+    else if (remaining > (total >> (2 * GS2D_PRIO_SHIFT))) __builtin_amdgcn_s_setprio(2);
+    else if (remaining > (total >> (3 * GS2D_PRIO_SHIFT))) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
+}
+#else
+__device__ __forceinline__ void prio_by_remaining(uint32_t, uint32_t) {}
+#endif
+
 // lane's position among the set bits of a ballot below it
 __device__ __forceinline__ int rank_below(uint64_t b)
 {
@@ -204,21 +237,29 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     // quadrant are fetched and staged, and chunks keep being added until the 64 LDS slots are full.  A chunk that does not
     // fit is split: the lanes left over keep their cull bits (carry_tm) and are staged first in the next batch.
     uint32_t next_chunk = range.x;  // absolute index of the next chunk to read
-    uint32_t carry_base = 0;
-    uint32_t carry_tm = 0u;
+    uint32_t carry_base = 0, carry_tm = 0u, carry_id = 0u;
     bool carry = false;
+    // the cull bits and the Gaussian id of chunk `next_chunk` are always in flight one chunk ahead (unconditional loads,
+    // index clamped to the list), so that the record gather is the only serial memory round trip of a chunk
+    const uint32_t last_i = range.y > range.x ? range.y - 1u : range.x;
+    uint32_t pf_tm = hits[(size_t)min(next_chunk + lane, last_i) * 4 + wave];
+    uint32_t pf_id = point_list[min(next_chunk + lane, last_i)];
     for (;;) {
         if (__ballot(!done) == 0) break;
+        prio_by_remaining(range.y - min(next_chunk, range.y), range.y - range.x);
         int fill = 0;
         GS2D_PROF_STAGE_BEGIN();
         wave_lds_sync();  // previous batch fully consumed before it is overwritten
         for (;;) {
-            uint32_t cbase, tm;
-            if (carry) { cbase = carry_base; tm = carry_tm; carry = false; }
+            uint32_t cbase, tm, id;
+            if (carry) { cbase = carry_base; tm = carry_tm; id = carry_id; carry = false; }
             else {
                 if (next_chunk >= range.y) break;
                 cbase = next_chunk; next_chunk += 64;
-                tm = cbase + lane < range.y ? hits[(size_t)(cbase + lane) * 4 + wave] : 0u;
+                tm = cbase + lane < range.y ? pf_tm : 0u;
+                id = pf_id;
+                pf_tm = hits[(size_t)min(next_chunk + lane, last_i) * 4 + wave];
+                pf_id = point_list[min(next_chunk + lane, last_i)];
             }
             const uint64_t tb = __ballot(tm != 0u);
             const int c = __popcll(tb);
@@ -226,14 +267,13 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
             const int slot = fill + rank_below(tb);
             const bool take = tm != 0u && slot < 64;
             if (take) {
-                const uint32_t id = point_list[cbase + lane];
                 const float4* rp = rec + (size_t)id * GS2D_REC_F4;
                 const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
                 float4 r4 = rp[4];
                 r4.w = __uint_as_float(((cbase - range.x + lane) << 4) | tm);  // list position + cull bits ride in the free slot
                 wb.q[0][slot] = r0; wb.q[1][slot] = r1; wb.q[2][slot] = r2; wb.q[3][slot] = r3; wb.q[4][slot] = r4;
             }
-            if (fill + c > 64) { carry_tm = take ? 0u : tm; carry_base = cbase; carry = true; fill = 64; break; }
+            if (fill + c > 64) { carry_tm = take ? 0u : tm; carry_id = id; carry_base = cbase; carry = true; fill = 64; break; }
             fill += c;
             if (fill == 64) break;
         }
@@ -518,7 +558,9 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                  dn1 != 0.f || dn2 != 0.f || dL_dmedian_depth != 0.f || dL_dreg != 0.f) == 0)
         return;
     const float final_A = 1 - T_final;
-    const float bg_dot = fmaf(bg[2], dpx2, fmaf(bg[1], dpx1, bg[0] * dpx0));
+    // background term of dL_dalpha, -T_final/(1-alpha) * dot(bg, dL_dpixel) (backward.cu:407-410): the two per-pixel factors
+    // are folded into one register (one rounding apart from the oracle's (-T_final * ioma) * bg_dot; exactly 0 for bg = 0)
+    const float tf_bg = T_final * fmaf(bg[2], dpx2, fmaf(bg[1], dpx1, bg[0] * dpx0));
     const float sa_k = 1.0f / (4 * fmaxf(mstd * (1.0f / (1 - T_final)), 1e-7f));  // per-pixel constant (IEEE, as the oracle)
     const float c1f = GS2D_FAR_N / (GS2D_FAR_N - GS2D_NEAR_N);
     float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
@@ -555,34 +597,53 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     GS2D_PROF_BEGIN();
     auto run = [&](auto dn_tag) __attribute__((always_inline)) {
     constexpr bool ANY_DN = decltype(dn_tag)::value;
+    if (max_last == 0u) return;  // no pixel of this quadrant has a contributor
     int chunk = (int)((max_last + 63) / 64) - 1;  // next chunk to read
     int carry_chunk = -1;                           // chunk whose shallower part is still waiting
-    uint32_t carry_tm = 0u;
+    uint32_t carry_tm = 0u, carry_id = 0u;
+    // cull bits and Gaussian ids of chunk `chunk` are always in flight one chunk ahead (unconditional loads, index
+    // clamped to the part of the list that matters), so the record gather is a chunk's only serial memory round trip
+    // (issued when a chunk is consumed and again right after a trip loop -- before the flush -- rather than kept alive
+    // through the trip loop: those two registers would push the loop over its 96-VGPR budget.)
+    const uint32_t last_i = range.x + max_last - 1u;
+#if GS2D_BWD_PREFETCH
+    uint32_t pf_tm = hits[(size_t)min(range.x + (uint32_t)chunk * 64u + lane, last_i) * 4 + wave];
+    uint32_t pf_id = point_list[min(range.x + (uint32_t)chunk * 64u + lane, last_i)];
+#endif
     for (;;) {
         int fill = 0;
+        prio_by_remaining((uint32_t)(chunk + 1), (max_last + 63u) / 64u);
         GS2D_PROF_STAGE_BEGIN();
         wave_lds_sync();  // previous batch fully consumed before it is overwritten
         for (;;) {
-            uint32_t tm;
+            uint32_t tm, my_id;
             int cb;
-            if (carry_chunk >= 0) { tm = carry_tm; cb = carry_chunk; carry_chunk = -1; }
+            if (carry_chunk >= 0) { tm = carry_tm; my_id = carry_id; cb = carry_chunk; carry_chunk = -1; }
             else {
                 if (chunk < 0) break;
                 cb = chunk--;
                 const int n = (int)min(64u, max_last - (uint32_t)cb * 64u);
-                // queues come from the cull bits the forward stored for this (instance, quadrant): no second cull test
-                tm = lane < n ? hits[(size_t)(range.x + (uint32_t)cb * 64u + lane) * 4 + wave] : 0u;
+                // queues come from the cull bits of this (instance, quadrant)
+#if GS2D_BWD_PREFETCH
+                tm = lane < n ? pf_tm : 0u;
+                my_id = pf_id;
+                const uint32_t nb = range.x + (uint32_t)max(chunk, 0) * 64u + lane;
+                pf_tm = hits[(size_t)min(nb, last_i) * 4 + wave];
+                pf_id = point_list[min(nb, last_i)];
+#else
+                const uint32_t at = min(range.x + (uint32_t)cb * 64u + lane, last_i);
+                tm = lane < n ? hits[(size_t)at * 4 + wave] : 0u;
+                my_id = point_list[at];  // unconditional and coalesced: issued together with the cull bits
+#endif
             }
             const uint64_t tb = __ballot(tm != 0u);
             const int c = __popcll(tb);
             if (c == 0) continue;
             // deepest touched lane -> highest free slot: touched lanes above me = c - 1 - (touched lanes below me)
-            const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(tb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tb, 0u));
-            const int slot = 64 - fill - c + below;
+            const int slot = 64 - fill - c + rank_below(tb);
             const bool take = tm != 0u && slot >= 0;
             if (take) {
                 const uint32_t pos = (uint32_t)cb * 64u + lane;
-                const uint32_t my_id = point_list[range.x + pos];
                 const float4* rp = rec + (size_t)my_id * GS2D_REC_F4;
                 const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
                 const float red = rp[3].w;
@@ -591,7 +652,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                 wb.q[3][slot] = make_float4(red, r4.x, r4.y, __uint_as_float(my_id));  // colour + the Gaussian id
                 wb.pn[slot] = (pos << 4) | tm;                                         // list position + cull bits
             }
-            if (fill + c > 64) { carry_tm = take ? 0u : tm; carry_chunk = cb; fill = 64; break; }
+            if (fill + c > 64) { carry_tm = take ? 0u : tm; carry_id = my_id; carry_chunk = cb; fill = 64; break; }
             fill += c;
             if (fill == 64) break;
         }
@@ -602,28 +663,27 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
         const uint32_t nib = lane >= 64 - fill ? wb.pn[lane] : 0u;
         const uint64_t m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u), m2 = __ballot(nib & 4u), m3 = __ballot(nib & 8u);
         const int len0 = __popcll(m0), len1 = __popcll(m1), len2 = __popcll(m2), len3 = __popcll(m3);
+        reinterpret_cast<uint32_t*>(wb.ql)[lane] = 0xFFFFFFFFu;  // every entry past a queue's end reads 255 = "exhausted"
         if (nib & 1u) wb.ql[0][len0 - 1 - rank_below(m0)] = (uint8_t)lane;
         if (nib & 2u) wb.ql[1][len1 - 1 - rank_below(m1)] = (uint8_t)lane;
         if (nib & 4u) wb.ql[2][len2 - 1 - rank_below(m2)] = (uint8_t)lane;
         if (nib & 8u) wb.ql[3][len3 - 1 - rank_below(m3)] = (uint8_t)lane;
         const int trips = max(max(len0, len1), max(len2, len3));  // >= 1: every staged splat touches some row
-        const int mylen = row_select(row8, len0, len1, len2, len3);
         wave_lds_sync();
         GS2D_PROF_STAGE_END();
         // software pipeline: queue entries are read two trips ahead, records one trip ahead
         int t = 0;
         uint32_t j = qrow[0], jx = qrow[1];
         float4 ga0 = wb.q[0][j & 63], ga1 = wb.q[1][j & 63], ga2 = wb.q[2][j & 63];
-        uint32_t gap = wb.pn[j & 63], gbp;
         float4 gb0, gb1, gb2;
-#define GS2D_BWD_STEP(G0, G1, G2, GP, J, N0_, N1_, N2_, NP_, JN)                                                                  \
+#define GS2D_BWD_STEP(G0, G1, G2, J, N0_, N1_, N2_, JN)                                                                  \
         {                                                                                                             \
             GS2D_PROF_TRIP();                                                                                         \
             const uint32_t jnn = qrow[t + 2];                                                                         \
-            N0_ = wb.q[0][JN & 63]; N1_ = wb.q[1][JN & 63]; N2_ = wb.q[2][JN & 63]; NP_ = wb.pn[JN & 63];             \
+            N0_ = wb.q[0][JN & 63]; N1_ = wb.q[1][JN & 63]; N2_ = wb.q[2][JN & 63];                                   \
             const float4 cc = wb.q[3][J & 63]; /* r, g, b, id */                                                      \
-            const uint32_t contributor = GP >> 4; /* list position, 0-based, as in backward.cu:285 */                 \
-            bool active = inside && t < mylen && contributor < last_contributor; /* t >= mylen: row queue exhausted */ \
+            const uint32_t contributor = wb.pn[J & 63] >> 4; /* list position, 0-based, as in backward.cu:285 */      \
+            bool active = J < 64u && contributor < last_contributor; /* J == 255: queue exhausted; outside: last = 0 */ \
             if (__ballot(active) != 0) {                                                                              \
                 /* Part A (all lanes): same geometry / alpha as the forward */                                        \
                 const float k0 = fmaf(pxf, G2.x, -G0.x), k1 = fmaf(pxf, G2.y, -G0.y), k2 = fmaf(pxf, G2.z, -G0.z);    \
@@ -699,7 +759,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                     }                                                                                                 \
                     dL_dalpha *= T;                                                                                   \
                     last_alpha = alpha;                                                                               \
-                    dL_dalpha = fmaf(-T_final * ioma, bg_dot, dL_dalpha);                                             \
+                    dL_dalpha = fmaf(-ioma, tf_bg, dL_dalpha);                                                        \
                     const float dL_dG = G2.w * dL_dalpha;                                                             \
                     dL_dz = fmaf(conf * w, dL_ddepth, dL_dz);                                                         \
                     d_w = w;                                                                                          \
@@ -753,10 +813,19 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
             if (++t >= trips) break;                                                                                  \
         }
         for (;;) {
-            GS2D_BWD_STEP(ga0, ga1, ga2, gap, j, gb0, gb1, gb2, gbp, jx)
-            GS2D_BWD_STEP(gb0, gb1, gb2, gbp, jx, ga0, ga1, ga2, gap, j)
+            GS2D_BWD_STEP(ga0, ga1, ga2, j, gb0, gb1, gb2, jx)
+            GS2D_BWD_STEP(gb0, gb1, gb2, jx, ga0, ga1, ga2, j)
         }
 #undef GS2D_BWD_STEP
+#if GS2D_BWD_PREFETCH
+        {   // re-issue the prefetch of the next chunk (see above; the opaque index keeps the compiler from reusing the copy
+            // it loaded before the trip loop, which would have to stay in registers through it)
+            uint32_t nb = range.x + (uint32_t)max(chunk, 0) * 64u + lane;
+            asm volatile("" : "+v"(nb));
+            pf_tm = hits[(size_t)min(nb, last_i) * 4 + wave];
+            pf_id = point_list[min(nb, last_i)];
+        }
+#endif
         // flush: every touched splat of the batch goes to its global record once, four splats (one per row) per pass
         // two passes (eight splats) per iteration so the LDS round trips of one pass hide behind the other
         const int flush_off = li < 3 ? li : (li < 12 ? li + 3 : 15);  // accumulator li -> offset in the gradient record

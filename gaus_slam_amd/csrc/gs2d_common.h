@@ -117,7 +117,8 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
                            const float* transMat_precomp, const float* colors_precomp, const CamParams& cam,
                            int* radii, float* depths, float4* rec, uint32_t* tiles_touched, uint8_t* clamped,
                            const float* pose_Rt, const float* pose_q, uint32_t* block_sums, hipStream_t s);
-void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float4* rec, const int* radii,
+// Gaussians [first, P)
+void launch_preprocess_bwd(int first, int P, int D, int M, const float* means3D, const float4* rec, const int* radii,
                            const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
                            const CamParams& cam, const float* grad_rec, float* dL_dtransMat, float* dL_dnormal,
                            float* dL_dcolor, float* dL_dopacity, float* dL_dsh, float* dL_dmean2D,

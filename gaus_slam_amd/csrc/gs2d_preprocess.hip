@@ -513,7 +513,7 @@ preprocess_bwd_one(int idx, int P, int D, int M, const float* __restrict__ means
 }
 
 __global__ void __launch_bounds__(256)
-preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float4* __restrict__ rec,
+preprocess_bwd_kernel(int first, int P, int D, int M, const float* __restrict__ means3D, const float4* __restrict__ rec,
                       const int* __restrict__ radii, const float* __restrict__ shs,
                       const uint8_t* __restrict__ clamped, const float* __restrict__ scales,
                       const float* __restrict__ rotations, const CamParams cam, const float* __restrict__ grad_rec,
@@ -522,7 +522,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       float* __restrict__ dL_dmean3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
                       const float* __restrict__ pose_Rt, const float* __restrict__ pose_q, float* __restrict__ dL_dpose)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = first + blockIdx.x * 256 + threadIdx.x;  // P = one past the last Gaussian of this launch's range
     // pose gradient: sum_i g_i (x) x_i and sum_i g_i over the Gaussians of this workgroup, then 12 atomics
     float pg[12];
 #pragma unroll
@@ -575,14 +575,15 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
                        rec, tiles_touched, clamped, pose_Rt, pose_q, block_sums);
 }
 
-void launch_preprocess_bwd(int P, int D, int M, const float* means3D, const float4* rec, const int* radii,
+void launch_preprocess_bwd(int first, int P, int D, int M, const float* means3D, const float4* rec, const int* radii,
                            const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
                            const CamParams& cam, const float* grad_rec, float* dL_dtransMat, float* dL_dnormal,
                            float* dL_dcolor, float* dL_dopacity, float* dL_dsh, float* dL_dmean2D,
                            float* dL_dmean3D, float* dL_dscale, float* dL_drot, const float* pose_Rt, const float* pose_q,
                            float* dL_dpose, hipStream_t s)
 {
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, rec, radii, shs,
+    if (P <= first) return;
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P - first + 255) / 256), dim3(256), 0, s, first, P, D, M, means3D, rec, radii, shs,
                        clamped, scales, rotations, cam, grad_rec, dL_dtransMat, dL_dnormal, dL_dcolor, dL_dopacity,
                        dL_dsh, dL_dmean2D, dL_dmean3D, dL_dscale, dL_drot, pose_Rt, pose_q, dL_dpose);
 }

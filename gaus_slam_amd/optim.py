@@ -33,7 +33,10 @@ def _views(flat, P):
 class GaussianSoA:
     """Flat [13*P] parameter buffer with per-field [P,k] views (leaf tensors that share storage with `flat`)."""
 
+    generation = 0  # bumped whenever the flat buffer is re-allocated (prune / cat): older leaves() are then stale
+
     def __init__(self, fields):
+        self.generation = self.generation + 1
         P = fields["means3D"].shape[0]
         dev = fields["means3D"].device
         self.P = P
@@ -43,8 +46,20 @@ class GaussianSoA:
             v.copy_(fields[name].detach().reshape(v.shape))
 
     def leaves(self, requires_grad=True):
-        """Per-field autograd leaves aliasing the flat buffer (what the rasterizer is called with)."""
-        return OrderedDict((n, v.detach().requires_grad_(requires_grad)) for n, v in self.views.items())
+        """Per-field autograd leaves aliasing the flat buffer (what the rasterizer is called with).  They are valid until
+        the next prune / cat, which re-allocates the buffer: fetch fresh leaves (and rebuild whatever holds the old ones,
+        e.g. a KeyframeShardedBA) afterwards -- `assert_current` tells the two apart."""
+        out = OrderedDict((n, v.detach().requires_grad_(requires_grad)) for n, v in self.views.items())
+        for t in out.values():
+            t._gs2d_generation = self.generation
+        return out
+
+    def assert_current(self, leaves):
+        """Raise if any tensor of `leaves` (a dict from leaves()) no longer aliases this buffer."""
+        for n, t in leaves.items():
+            v = self.views[n]
+            if getattr(t, "_gs2d_generation", None) != self.generation or t.data_ptr() != v.data_ptr() or t.shape != v.shape:
+                raise RuntimeError(f"stale Gaussian leaf {n!r}: the SoA was re-allocated by prune()/cat(); call leaves() again")
 
 
 class FusedGaussianAdam:
@@ -66,9 +81,13 @@ class FusedGaussianAdam:
             ends.append(o)
         return ends
 
-    def step(self, grad_flat):
-        """grad_flat: [13*P] fp32 in bucket layout (e.g. `GradBucket.flat` after the all-reduce)."""
+    def step(self, grad_flat, leaves=None):
+        """grad_flat: [13*P] fp32 in bucket layout (e.g. `GradBucket.flat` after the all-reduce).
+        leaves (optional): the dict the gradients were rendered from; a stale one (older than the last prune / cat) raises
+        instead of silently updating parameters nobody renders from."""
         soa = self.soa
+        if leaves is not None:
+            soa.assert_current(leaves)
         if grad_flat.numel() != soa.flat.numel() or grad_flat.dtype != torch.float32 or not grad_flat.is_contiguous():
             raise RuntimeError("grad_flat must be a contiguous fp32 [13*P] tensor in bucket layout")
         if not soa.flat.is_cuda or grad_flat.device != soa.flat.device:

@@ -9,6 +9,7 @@ it runs unchanged on PyTorch-ROCm.  All compute happens in the HIP library behin
 """
 import contextlib
 import ctypes as C
+import itertools
 from typing import NamedTuple
 
 import torch
@@ -42,13 +43,12 @@ class _Chunk:
     costs tens of microseconds); the `user` pointer the C side passes back selects the live _Chunk."""
 
     _live = {}
-    _next = [1]
+    _next = itertools.count(1)  # next() on a count is atomic under the GIL: concurrent host threads never share a key
 
     def __init__(self, device):
         self.device = device
         self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
-        self.key = _Chunk._next[0]
-        _Chunk._next[0] += 1
+        self.key = next(_Chunk._next)
         _Chunk._live[self.key] = self
         self.cb = _CHUNK_CB
         self.user = C.c_void_p(self.key)
@@ -117,31 +117,34 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     radii = alloc((P,), dtype=torch.int32, device=dev)
     geom, binning, img = _Chunk(dev), _Chunk(dev), _Chunk(dev)
     rendered = 0
-    if P != 0:
-        M = sh.size(1) if sh.size(0) != 0 else 0
-        keep = [_f32c(t) for t in (background, means3D, sh, colors, opacity, scales, rotations, transMat_precomp,
-                                   viewmatrix, projmatrix, campos)]
-        bg_, m3_, sh_, col_, op_, sc_, rot_, tm_, vm_, pm_, cp_ = keep
-        with _on_device(dev):
-            prt_ = _f32c(pose_Rt) if pose_Rt is not None else None
-            pq_ = _f32c(pose_quat) if pose_quat is not None else None
-            rendered = L.gs2d_forward_posed(
-                geom.cb, geom.user, binning.cb, binning.user, img.cb, img.user, P, int(degree), M, _ptr(bg_), W, H, _ptr(m3_),
-                _ptr(sh_), _ptr(col_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(tm_), _ptr(vm_),
-                _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), out_color.data_ptr(),
-                out_others.data_ptr(), radii.data_ptr(), int(bool(use_sa)), int(bool(debug)), _ptr(prt_), _ptr(pq_),
-                _stream_ptr(dev))
+    try:
+        if P != 0:
+            M = sh.size(1) if sh.size(0) != 0 else 0
+            keep = [_f32c(t) for t in (background, means3D, sh, colors, opacity, scales, rotations, transMat_precomp,
+                                       viewmatrix, projmatrix, campos)]
+            bg_, m3_, sh_, col_, op_, sc_, rot_, tm_, vm_, pm_, cp_ = keep
+            with _on_device(dev):
+                prt_ = _f32c(pose_Rt) if pose_Rt is not None else None
+                pq_ = _f32c(pose_quat) if pose_quat is not None else None
+                rendered = L.gs2d_forward_posed(
+                    geom.cb, geom.user, binning.cb, binning.user, img.cb, img.user, P, int(degree), M, _ptr(bg_), W, H,
+                    _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(tm_),
+                    _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                    out_color.data_ptr(), out_others.data_ptr(), radii.data_ptr(), int(bool(use_sa)), int(bool(debug)),
+                    _ptr(prt_), _ptr(pq_), _stream_ptr(dev))
+    finally:  # the callback registry never keeps a chunk of a call that raised
         for ch in (geom, binning, img):
             ch.release()
-        if rendered < 0:
-            raise RuntimeError(_lib.last_error())
+    if rendered < 0:
+        raise RuntimeError(_lib.last_error())
     return rendered, out_color, out_others, radii, geom.tensor, binning.tensor, img.tensor
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, use_sa,
-                                 debug, pose_Rt=None, pose_quat=None, grad_sink=None, lean=False, pose_only_out=None):
+                                 debug, pose_Rt=None, pose_quat=None, grad_sink=None, lean=False, pose_only_out=None,
+                                 chunk_rows=None, on_chunk=None):
     """_C.rasterize_gaussians_backward (rasterize_points.cu:140-239): returns
     (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dtransMat[P,9], dL_dsh[P,M,3],
      dL_dscales[P,2], dL_drotations[P,4]).
@@ -151,7 +154,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     lean (used by the autograd node): skip the outputs nobody can observe there -- the internal dL_dnormal and, when no
     cov3D_precomp was given, dL_dtransMat (returned as None): 48 B per Gaussian less to write.
     pose_only_out (tracking): a zeroed float32 tensor whose first 12 elements receive dL/d[R|t]; no per-Gaussian gradient
-    is computed or allocated and only that tensor is returned."""
+    is computed or allocated and only that tensor is returned.
+    chunk_rows / on_chunk (keyframe-sharded BA): run the per-Gaussian stage in chunks of `chunk_rows` Gaussians
+    (gs2d_backward_staged) and call on_chunk(g_begin, g_end) after each chunk has been enqueued -- the caller starts that
+    chunk's gradient all-reduce there, so it overlaps with the next chunk's kernel."""
     for name, t in (("background", background), ("means3D", means3D), ("radii", radii), ("colors", colors),
                     ("scales", scales), ("rotations", rotations), ("transMat_precomp", transMat_precomp),
                     ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("sh", sh), ("campos", campos),
@@ -206,14 +212,25 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             prt_ = _f32c(pose_Rt) if pose_Rt is not None else None
             pq_ = _f32c(pose_quat) if pose_quat is not None else None
             dL_dpose = torch.empty((3, 4), dtype=torch.float32, device=dev) if pose_Rt is not None else None
-            rc = L.gs2d_backward_posed(
-                P, int(degree), M, int(R), _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(sc_),
-                float(scale_modifier), _ptr(rot_), _ptr(tm_), _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx),
-                float(tan_fovy), radii_.data_ptr(), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
-                dc_.data_ptr(), do_.data_ptr(), dL_dmeans2D.data_ptr(), _ptr(dL_dnormal), dL_dopacity.data_ptr(),
-                dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), _ptr(dL_dtransMat), _ptr(dL_dsh),
-                dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(use_sa)), int(bool(debug)), _ptr(prt_),
-                _ptr(pq_), _ptr(dL_dpose), _stream_ptr(dev))
+            tail = (P, int(degree), M, int(R), _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(sc_),
+                    float(scale_modifier), _ptr(rot_), _ptr(tm_), _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx),
+                    float(tan_fovy), radii_.data_ptr(), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+                    dc_.data_ptr(), do_.data_ptr(), dL_dmeans2D.data_ptr(), _ptr(dL_dnormal), dL_dopacity.data_ptr(),
+                    dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), _ptr(dL_dtransMat), _ptr(dL_dsh),
+                    dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(use_sa)), int(bool(debug)), _ptr(prt_),
+                    _ptr(pq_), _ptr(dL_dpose), _stream_ptr(dev))
+            if on_chunk is None:
+                rc = L.gs2d_backward_posed(*tail)
+            else:
+                rows = max(1, int(chunk_rows or P))
+                rc = L.gs2d_backward_staged(1, 0, 0, *tail)  # GS2D_BWD_BLEND
+                g0 = 0
+                while rc >= 0 and g0 < P:
+                    g1 = min(P, g0 + rows)
+                    rc = L.gs2d_backward_staged(2, g0, g1, *tail)  # GS2D_BWD_PREPROCESS on [g0, g1)
+                    if rc >= 0:
+                        on_chunk(g0, g1)
+                    g0 = g1
         if rc < 0:
             raise RuntimeError(_lib.last_error())
         if pose_Rt is not None:
@@ -242,20 +259,40 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 
 class _Sink:  # process-wide on purpose: autograd runs CUDA backward nodes on its own device thread, not the caller's
     views = None
+    chunk_rows = None
+    on_chunk = None
+    armed = False     # a grad_sink context is active
+    consumed = False  # ... and one operator backward has already taken it
 
 
 _SINK = _Sink()
 
 
 @contextlib.contextmanager
-def grad_sink(views):
-    """While active, the NEXT operator backward in this process writes its parameter gradients into `views`
-    (see rasterize_gaussians_backward).  Used by ba_shard to produce gradients directly in the all-reduce bucket."""
-    _SINK.views = views
+def grad_sink(views, chunk_rows=None, on_chunk=None):
+    """While active, the ONE operator backward that runs in this process writes its parameter gradients into `views`
+    (see rasterize_gaussians_backward).  Used by ba_shard to produce gradients directly in the all-reduce bucket.
+    A second operator backward inside the same context raises: its gradients would silently land in fresh tensors while
+    the caller believes they are in `views` (e.g. a loss function that renders twice)."""
+    if _SINK.armed:
+        raise RuntimeError("grad_sink contexts cannot be nested")
+    _SINK.views, _SINK.armed, _SINK.consumed = views, True, False
+    _SINK.chunk_rows, _SINK.on_chunk = chunk_rows, on_chunk
     try:
         yield
     finally:
-        _SINK.views = None
+        _SINK.views, _SINK.armed, _SINK.consumed = None, False, False
+        _SINK.chunk_rows, _SINK.on_chunk = None, None
+
+
+def _take_sink():
+    if not _SINK.armed:
+        return None, None, None
+    if _SINK.consumed:
+        raise RuntimeError("a second rasterizer backward ran inside one grad_sink context: only one operator call per "
+                           "direct-gradient backward is supported (render once per keyframe, or use direct_grads=False)")
+    _SINK.consumed = True
+    return _SINK.views, _SINK.chunk_rows, _SINK.on_chunk
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -281,13 +318,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
-        sink = getattr(_SINK, "views", None)
-        _SINK.views = None  # one backward per sink
+        sink, chunk_rows, on_chunk = _take_sink()  # one backward per sink; a second one raises
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, sh, rs.sh_degree, rs.campos, geomBuffer,
-            ctx.num_rendered, binningBuffer, imgBuffer, rs.use_sa, rs.debug, grad_sink=sink, lean=True)
+            ctx.num_rendered, binningBuffer, imgBuffer, rs.use_sa, rs.debug, grad_sink=sink, lean=True,
+            chunk_rows=chunk_rows, on_chunk=on_chunk)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
                 grad_cov3Ds_precomp, None)
 

@@ -30,6 +30,13 @@
  *   - return value < 0 signals an error; gs2d_last_error() describes it.
  *     (The reference throws std::runtime_error / AT_ERROR.)
  *
+ * Deliberately dropped from the reference signatures: forward's `out_mask` ([1,H,W], allocated by
+ * RasterizeGaussiansCUDA -- rasterize_points.cu:89 -- and passed to Rasterizer::forward, rasterizer.h:42-71, but never
+ * written or read by any kernel), the unused `focal_x/focal_y` blend arguments and `tan_fov*` of the forward preprocess
+ * (forward.cu:264-268) -- tan_fovx/tan_fovy are still accepted here because the BACKWARD rebuilds W and H from them
+ * (backward.cu:641-642).  The per-stage timing helpers (gs2d_stage_timing_*) are a bench facility: process-global and not
+ * thread-safe.
+ *
  * No torch types appear in this header.  The reference-side binding a
  * maintainer would write is shown in INTEGRATION.md.
  */
@@ -126,6 +133,27 @@ int gs2d_forward_posed(
     float* out_others, int* radii, int use_sa, int debug, const float* pose_Rt, const float* pose_quat, void* stream);
 
 int gs2d_backward_posed(
+    int P, int D, int M, int R, const float* background, int width, int height, const float* means3D, const float* shs,
+    const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+    const float* transMat_precomp, const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+    float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix,
+    const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+    float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot, int use_sa, int debug, const float* pose_Rt,
+    const float* pose_quat, float* dL_dpose /* [12] */, void* stream);
+
+/*
+ * The backward in two stages, the second one on a range of Gaussians (no counterpart in the reference, whose backward is one
+ * call -- rasterizer_impl.cu:354-460): stage GS2D_BWD_BLEND clears the per-Gaussian gradient records and runs the blend
+ * backward over the whole image; stage GS2D_BWD_PREPROCESS turns the records of Gaussians [g_begin, g_end) into the dL_*
+ * outputs (same full-size output pointers; only rows of that range are written).  A caller that shards keyframes over GPUs
+ * (gaus_slam_amd/ba_shard.py) runs BLEND once and PREPROCESS chunk by chunk, starting the gradient all-reduce of a chunk
+ * while the next chunk is still being computed.  gs2d_backward_posed == stages 3 on [0, P).  dL_dpose accumulates over the
+ * PREPROCESS calls and is cleared by the BLEND call.
+ */
+#define GS2D_BWD_BLEND 1
+#define GS2D_BWD_PREPROCESS 2
+int gs2d_backward_staged(
+    int stages, int g_begin, int g_end,
     int P, int D, int M, int R, const float* background, int width, int height, const float* means3D, const float* shs,
     const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
     const float* transMat_precomp, const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,

@@ -455,6 +455,101 @@ void orc_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_l
 }
 
 /*
+ * One pixel of the forward blend with selected knife-edge decisions inverted (test infrastructure for the parity
+ * tests): every discrete decision of forward.cu:350-436 whose operand lies within `knife` (relative) of its threshold
+ * is numbered in the order it is met; bit i of `flipmask` inverts decision i.  flipmask = 0 reproduces orc_blend_fwd
+ * for that pixel exactly.  A 1-ulp difference in expf / rcp can legitimately flip such a decision, so a GPU value at a
+ * knife-edge pixel has to equal ONE of these variants.  Returns the number of knife-edge decisions met.
+ * out[13] = color[3], others[7], last_contributor, median_contributor, final_T.
+ */
+int orc_blend_fwd_pixel(int W, int H, int px, int py, const uint32_t* ranges, const uint32_t* point_list,
+                        const float* means2D, const float* features, const float* transMats,
+                        const float* normal_opacity, const float* bg, int use_sa, float knife, uint32_t flipmask,
+                        float* out)
+{
+    const int gx = (W + TILE - 1) / TILE;
+    (void)H;
+    const int tile = (py / TILE) * gx + (px / TILE);
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    const float pxf = (float)px, pyf = (float)py;
+    float T = 1.0f, C[3] = {0, 0, 0}, N[3] = {0, 0, 0};
+    float Dp = 0, M1 = 0, M2 = 0, D2 = 0, distortion = 0, median_depth = 0;
+    float median_contributor = -1;
+    uint32_t contributor = 0, last_contributor = 0;
+    int nk = 0;
+#define KNIFE_DECIDE(cond, a, b)                                                           \
+    ({ int d_ = (cond);                                                                     \
+       if (relm((a), (b)) <= knife) { if (nk < 32 && ((flipmask >> nk) & 1u)) d_ = !d_; nk++; } \
+       d_; })
+    for (uint32_t it = r0; it < r1; it++) {
+        contributor++;
+        const uint32_t g = point_list[it];
+        const float* Tm = transMats + 9 * (size_t)g;
+        const float Tu[3] = {Tm[0], Tm[1], Tm[2]}, Tv[3] = {Tm[3], Tm[4], Tm[5]}, Tw[3] = {Tm[6], Tm[7], Tm[8]};
+        const float k[3] = {fmaf(pxf, Tw[0], -Tu[0]), fmaf(pxf, Tw[1], -Tu[1]), fmaf(pxf, Tw[2], -Tu[2])};
+        const float l[3] = {fmaf(pyf, Tw[0], -Tv[0]), fmaf(pyf, Tw[1], -Tv[1]), fmaf(pyf, Tw[2], -Tv[2])};
+        const float p0 = fmaf(k[1], l[2], -(k[2] * l[1]));
+        const float p1 = fmaf(k[2], l[0], -(k[0] * l[2]));
+        const float p2 = fmaf(k[0], l[1], -(k[1] * l[0]));
+        if (p2 == 0.0f) continue;
+        const float ip = 1.0f / p2;
+        const float s0 = p0 * ip, s1 = p1 * ip;
+        const float rho3d = fmaf(s0, s0, s1 * s1);
+        const float d0 = means2D[2 * (size_t)g] - pxf, d1 = means2D[2 * (size_t)g + 1] - pyf;
+        const float rho2d = FILTER_INV_SQ * fmaf(d0, d0, d1 * d1);
+        const float mx = fmaxf(rho3d, rho2d);
+        int ray = rho3d <= rho2d;
+        if (mx > 0 && fabsf(rho3d - rho2d) / mx <= knife) { if (nk < 32 && ((flipmask >> nk) & 1u)) ray = !ray; nk++; }
+        const float rho = ray ? rho3d : rho2d;
+        float depth = ray ? fmaf(s0, Tw[0], fmaf(s1, Tw[1], Tw[2])) : Tw[2];
+        if (KNIFE_DECIDE(depth < NEAR_N, depth, NEAR_N)) continue;
+        const float* no = normal_opacity + 4 * (size_t)g;
+        const float power = -0.5f * rho;
+        if (power > 0.0f) continue;
+        const float alpha = fmin_c(0.99f, no[3] * expf(power));
+        if (KNIFE_DECIDE(alpha < 1.0f / 255.0f, alpha, 1.0f / 255.0f)) continue;
+        const float test_T = T * (1 - alpha);
+        if (KNIFE_DECIDE(test_T < 0.0001f, test_T, 0.0001f)) break;
+        const float w = alpha * T;
+        if (KNIFE_DECIDE(T > 0.5f, T, 0.5f)) { median_depth = depth; median_contributor = (float)contributor; }
+        if (use_sa) {
+            if (Dp > 0) {
+                const float exp_depth = median_depth;
+                float exp_std = fmaf(fmaf(-2.0f * Dp, exp_depth, D2), 1.0f / (1 - T), exp_depth * exp_depth);
+                exp_std = fmax_c(exp_std, 1e-7f);
+                const float e = exp_depth - depth;
+                const float conf = expf(-(e * e) * (1.0f / (4 * exp_std)));
+                depth = fmaf(conf, depth, (1 - conf) * exp_depth);
+            }
+            Dp = fmaf(depth, w, Dp);
+            D2 = fmaf(depth * depth, w, D2);
+        } else {
+            const float A = 1 - T;
+            const float m = (FAR_N / (FAR_N - NEAR_N)) * (1 - NEAR_N * (1.0f / depth));
+            distortion = fmaf(fmaf(m * m, A, fmaf(-2.0f * m, M1, M2)), w, distortion);
+            Dp = fmaf(depth, w, Dp);
+            M1 = fmaf(m, w, M1);
+            M2 = fmaf(m * m, w, M2);
+        }
+        for (int ch = 0; ch < 3; ch++) N[ch] = fmaf(no[ch], w, N[ch]);
+        for (int ch = 0; ch < 3; ch++) C[ch] = fmaf(features[3 * (size_t)g + ch], w, C[ch]);
+        T = test_T;
+        last_contributor = contributor;
+    }
+#undef KNIFE_DECIDE
+    for (int ch = 0; ch < 3; ch++) out[ch] = fmaf(T, bg[ch], C[ch]);
+    out[3] = Dp;
+    out[4] = 1 - T;
+    for (int ch = 0; ch < 3; ch++) out[5 + ch] = N[ch];
+    out[8] = median_depth;
+    out[9] = use_sa ? fmaf(median_depth * median_depth, 1 - T, fmaf(-2.0f * median_depth, Dp, D2)) : distortion;
+    out[10] = (float)last_contributor;
+    out[11] = median_contributor < 0 ? 0.f : median_contributor;
+    out[12] = T;
+    return nk;
+}
+
+/*
  * Stage: backward blend.  backward.cu:143-463 (renderCUDA), one pixel at a
  * time, splats back to front.  Accumulators are double (see header).
  * acc layout per Gaussian (20 doubles): [0..2] dL_dcolor, [3..5] dL_dnormal,

@@ -140,6 +140,29 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, t
     return st
 
 
+def pixel_variants(st, px, py, knife, max_decisions=6):
+    """All outcomes of the forward blend at pixel (px, py) when the decisions within `knife` (relative) of their threshold
+    are flipped in every combination (orc_blend_fwd_pixel).  Returns (n_decisions, list of dicts color[3], others[7],
+    last_contributor, median_contributor, final_T); n_decisions > max_decisions returns only the unflipped variant."""
+    L = lib()
+    L.orc_blend_fwd_pixel.restype = C.c_int
+    features = st["colors_precomp"] if st["colors_precomp"] is not None else st["rgb"]
+    tm = st["transMat_precomp"] if st["transMat_precomp"] is not None else st["transMats"]
+
+    def one(mask):
+        out = np.zeros(13, np.float32)
+        nk = L.orc_blend_fwd_pixel(C.c_int(st["W"]), C.c_int(st["H"]), C.c_int(int(px)), C.c_int(int(py)), _p(st["ranges"]),
+                                   _p(st["point_list"]), _p(st["means2D"]), _p(features), _p(tm), _p(st["normal_opacity"]),
+                                   _p(st["bg"]), C.c_int(int(st["use_sa"])), C.c_float(knife), C.c_uint32(mask), _p(out))
+        return nk, dict(color=out[0:3].copy(), others=out[3:10].copy(), last_contributor=int(out[10]),
+                        median_contributor=int(out[11]), final_T=float(out[12]))
+
+    nk, base = one(0)
+    if nk == 0 or nk > max_decisions:
+        return nk, [base]
+    return nk, [base] + [one(m)[1] for m in range(1, 1 << nk)]
+
+
 def backward(st, dL_dcolor, dL_dallmap):
     """Backward for a forward() state.  Returns the 8 gradients of
     RAST/rasterize_points.cu:238 (+ the internal dL_dnormal)."""

@@ -215,3 +215,27 @@ def test_knn_oracle_matches_kdtree(oracle):
 def test_higher_msb(oracle):
     # rasterizer_impl.cu:35-50: bits needed for the tile id (7/11/12/12/11 for configs A/B/R/S)
     assert [oracle.higher_msb(n) for n in (80, 1200, 3225, 4015, 2035)] == [7, 11, 12, 12, 11]
+
+
+def test_batched_pure_pytorch_render_matches_c_oracle(oracle):
+    """oracle/torch_batched.py (the pure-PyTorch CPU baseline of bench.py, all tiles in lock-step) restates the same
+    forward as the C oracle: indices bit-exact, images to float32 conditioning on stable pixels, and it is differentiable."""
+    import torch
+    from oracle import torch_batched
+    from tests import util
+    for P, W, H, use_sa in ((256, 160, 120, True), (1500, 150, 100, False)):
+        sc = util.make_scene(P, W, H, seed=3, regime="mapping")
+        cam = sc["cam"]
+        bg = (0.2, 0.5, 0.1)
+        o = util.oracle_forward(oracle, sc, use_sa=use_sa, bg=bg)
+        leaves = {k: sc[k].clone().requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "colors")}
+        r = torch_batched.render(leaves["means3D"], leaves["scales"], leaves["rotations"], leaves["opacities"], leaves["colors"],
+                                 cam.viewmatrix, cam.projmatrix, W, H, bg=torch.tensor(bg), use_sa=use_sa)
+        assert np.array_equal(r["point_list"].numpy(), o["point_list"]) and np.array_equal(r["ranges"].numpy(), o["ranges"])
+        np.testing.assert_array_equal(r["radii"].numpy(), o["radii"])
+        stable = (o["stability"] > 2e-5).reshape(H, W)
+        np.testing.assert_array_equal(r["n_contrib"][0].numpy()[stable], o["n_contrib"][:H * W].reshape(H, W)[stable])
+        assert np.abs(r["color"].detach().numpy() - o["color"])[:, stable].max() <= 1e-4
+        assert np.abs(r["allmap"].detach().numpy() - o["allmap"])[:, stable].max() <= 1e-3
+        (r["color"].sum() + r["allmap"][:2].sum()).backward()
+        assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in leaves.values())

@@ -119,3 +119,31 @@ def grad_err(a, b):
     if b.size == 0:
         return 0.0
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def check_knife_pixels(orc, o, h, stable, tol, knife, scale=None):
+    """Knife-edge pixels (a discrete decision of the blend within `knife` of its threshold in the oracle) are excluded from
+    the plain L-inf comparison because a 1-ulp difference of v_exp_f32 / v_rcp_f32 may flip that decision.  They are not
+    unchecked: the HIP pixel must equal the oracle's pixel under ONE of the possible outcomes of those decisions
+    (oracle.pixel_variants enumerates them).  Returns (n_pixels, max_err over the matched variants); raises on a pixel
+    that matches no variant.  scale: optional per-channel magnitudes for the 7 allmap channels (stress scenes)."""
+    H, W = stable.shape
+    HW = H * W
+    ys, xs = np.nonzero(~stable)
+    worst = 0.0
+    sc = np.ones(7) if scale is None else np.asarray(scale, np.float64)
+    for y, x in zip(ys.tolist(), xs.tolist()):
+        nk, variants = orc.pixel_variants(o, x, y, knife)
+        best = None
+        for v in variants:
+            if v["last_contributor"] != int(h["last_contributor"][y, x]) or v["median_contributor"] != int(h["median_contributor"][y, x]):
+                continue
+            e = max(float(np.abs(h["color"][:, y, x] - v["color"]).max()),
+                    float((np.abs(h["allmap"][:, y, x] - v["others"]) / sc).max()))
+            best = e if best is None else min(best, e)
+        assert best is not None and best <= tol, (
+            f"knife-edge pixel ({x},{y}) with {nk} near-threshold decisions matches none of the {len(variants)} oracle outcomes "
+            f"(best err {best})")
+        worst = max(worst, best)
+    print(f"knife-edge pixels: {len(ys)} of {HW} ({len(ys) / HW:.2e}), all matched an oracle outcome, max err {worst:.2e}")
+    return len(ys), worst
