@@ -26,6 +26,7 @@ class GradBucket:
     def __init__(self, P, device):
         self.P = P
         self.flat = torch.zeros(BUCKET_FLOATS * P, dtype=torch.float32, device=device)
+        self._pending = []
         self.views = OrderedDict()
         o = 0
         for name, k in BUCKET_FIELDS.items():
@@ -47,6 +48,30 @@ class GradBucket:
                 self.flat.div_(dist.get_world_size(group))
         return self.flat
 
+    def reduce_rows(self, g0, g1, group=None):
+        """Start the all-reduce(sum) of Gaussians [g0, g1): the five field slices as ONE coalesced, asynchronous collective
+        (a single grouped launch under RCCL).  Called while later rows are still being computed; finish with wait()."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1) or g1 <= g0:
+            return
+        if dist.get_backend(group) == "nccl" or not self.flat.is_cuda:
+            dev = self.flat.device if self.flat.is_cuda else None
+            with dist._coalescing_manager(group=group, device=dev, async_ops=True) as cm:
+                for v in self.views.values():
+                    dist.all_reduce(v[g0:g1], op=dist.ReduceOp.SUM, group=group)
+            self._pending.append(cm)
+        else:  # gloo on device tensors (single-GPU rehearsal): no coalesced form, five asynchronous collectives
+            for v in self.views.values():
+                self._pending.append(dist.all_reduce(v[g0:g1], op=dist.ReduceOp.SUM, group=group, async_op=True))
+
+    def wait(self, group=None, average=False):
+        """Complete every reduce_rows() issued so far."""
+        for cm in self._pending:
+            cm.wait()
+        self._pending = []
+        if average and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            self.flat.div_(dist.get_world_size(group))
+        return self.flat
+
 
 def shard_keyframes(keyframes, rank, world_size):
     """Keyframe k of the batch goes to rank k % world_size (independent units, no data-path exchange)."""
@@ -58,11 +83,15 @@ class KeyframeShardedBA:
     render_loss_fn(params, keyframe) -> scalar loss OR (outputs, upstream_grads) pair for torch.autograd.backward.
     """
 
-    def __init__(self, params, render_loss_fn, group=None, average=False, direct_grads=False, streams=2):
+    def __init__(self, params, render_loss_fn, group=None, average=False, direct_grads=False, streams=2, overlap_chunks=4):
         """direct_grads: let the rasterizer's backward write the parameter gradients straight into the bucket (no pack
         copies).  Safe in every case -- a gradient that did not land in the bucket (the op was not fed the leaf itself,
-        e.g. activations in between) is packed by copy as before."""
+        e.g. activations in between) is packed by copy as before.
+        overlap_chunks: with direct_grads and one keyframe per rank, the per-Gaussian stage of the backward runs in that
+        many chunks of Gaussian indices and each chunk's gradients are all-reduced while the next chunk is computed
+        (SURVEY.md section 8(e)); 1 = one all-reduce of the whole bucket after the backward."""
         self.direct_grads = direct_grads
+        self.overlap_chunks = max(1, int(overlap_chunks))
         # A rank that holds several keyframes of the batch renders them on `streams` HIP streams (forwards first, then
         # backwards): at 640x480 one frame has 4800 quadrant-waves for 1024 SIMDs, so the kernels of a second frame
         # fill the idle tails and the latency-bound binning stages of the first (measured: 1.34 vs 1.52 ms per pair).
@@ -83,14 +112,14 @@ class KeyframeShardedBA:
     def rank(self):
         return dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
 
-    def local_backward(self, keyframe, sink=None):
+    def local_backward(self, keyframe, sink=None, chunk_rows=None, on_chunk=None):
         for p in self.params.values():
             p.grad = None
         res = self.fn(self.params, keyframe)
         ctx = contextlib.nullcontext()
         if sink is not None:
             from . import rasterizer
-            ctx = rasterizer.grad_sink(sink)
+            ctx = rasterizer.grad_sink(sink, chunk_rows=chunk_rows, on_chunk=on_chunk)
         with ctx:
             if isinstance(res, tuple):
                 outs, ups = res
@@ -98,6 +127,16 @@ class KeyframeShardedBA:
             else:
                 res.backward()
         return {k: p.grad for k, p in self.params.items()}
+
+    def gather_frame_params(self, local_params):
+        """All-gather of the rank-local per-keyframe parameters after a step (pose quaternion 4 + translation 3 + exposure 2
+        = 9 scalars in the reference, scene/Frame.py:84-92): [n] -> [world_size, n], row r = rank r's keyframe."""
+        t = local_params.detach().reshape(-1).contiguous()
+        if self.world_size == 1:
+            return t.unsqueeze(0).clone()
+        out = torch.empty(self.world_size * t.numel(), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        return out.view(self.world_size, t.numel())
 
     def _multi_stream_grads(self, mine):
         """Per-keyframe gradient dicts, keyframes spread over the side streams; joined to the current stream on return."""
@@ -142,6 +181,30 @@ class KeyframeShardedBA:
             g = self.local_backward(mine[0], self.bucket.views if self.direct_grads else None)
             return OrderedDict((name, g[name].reshape(v.shape) if g.get(name) is not None else torch.zeros_like(v))
                                for name, v in self.bucket.views.items())
+        P = self.bucket.P
+        # Chunked, overlapped reduction: decided from GLOBAL facts only (every rank must issue the same collectives):
+        # exactly one keyframe per rank, gradients written straight into the bucket.
+        if self.direct_grads and self.overlap_chunks > 1 and len(keyframes) == self.world_size and self.params["means3D"].is_cuda:
+            rows = -(-P // self.overlap_chunks)
+            done = []
+
+            def on_chunk(g0, g1):
+                done.append((g0, g1))
+                self.bucket.reduce_rows(g0, g1, self.group)
+            g = self.local_backward(mine[0], self.bucket.views, chunk_rows=rows, on_chunk=on_chunk)
+            stale = [n for n, v in self.bucket.views.items() if g.get(n) is None or g[n].data_ptr() != v.data_ptr()]
+            if not done:  # the operator was not reached with the leaves themselves: nothing has been reduced yet
+                self.bucket.pack(g)
+                self.bucket.all_reduce(self.group, self.average)
+                return self.bucket.views
+            self.bucket.wait(self.group, self.average)
+            for n in stale:  # a gradient that did not land in the bucket: copy it in and reduce that field on its own
+                v = self.bucket.views[n]
+                v.copy_(g[n].reshape(v.shape)) if g.get(n) is not None else v.zero_()
+                dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+                if self.average:
+                    v.div_(self.world_size)
+            return self.bucket.views
         if not mine:
             self.bucket.flat.zero_()
         elif len(mine) > 1 and self.n_streams > 1 and self.params["means3D"].is_cuda:

@@ -80,3 +80,56 @@ def test_bucket_layout_and_sharding():
     assert ba_shard.shard_keyframes(list(range(5)), 1, 2) == [1, 3]
     b.pack({"means3D": torch.ones(10, 3)})
     assert b.flat[:30].sum() == 30 and b.flat[30:].abs().sum() == 0
+
+
+def _worker_chunks(rank, world, port, P, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b = ba_shard.GradBucket(P, "cpu")
+        g = torch.Generator().manual_seed(100 + rank)
+        b.flat.copy_(torch.randn(b.flat.numel(), generator=g))
+        # the chunked, coalesced, asynchronous reduction the overlapped BA step issues (three ragged chunks)
+        for g0, g1 in ((0, 100), (100, 200), (200, P)):
+            b.reduce_rows(g0, g1)
+        b.wait()
+        ba = ba_shard.KeyframeShardedBA(_params(P), _fake_render_loss)
+        frames = ba.gather_frame_params(torch.arange(9, dtype=torch.float32) + 10 * rank)
+        if rank == 0:
+            q.put((b.flat.clone(), frames.clone()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chunked_reduce_rows_and_frame_param_gather():
+    """GradBucket.reduce_rows / wait (per-chunk coalesced all-reduce of the five field slices) sums exactly like one
+    all-reduce of the whole bucket, and gather_frame_params all-gathers the 9 rank-local pose / exposure scalars."""
+    P, world, port = 257, 2, 29533
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_chunks, args=(r, world, port, P, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    flat, frames = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = sum(torch.randn(13 * P, generator=torch.Generator().manual_seed(100 + r)) for r in range(world))
+    torch.testing.assert_close(flat, want, rtol=1e-6, atol=1e-6)
+    assert frames.shape == (2, 9) and torch.equal(frames[1], torch.arange(9, dtype=torch.float32) + 10)
+
+
+def test_second_backward_inside_one_grad_sink_raises():
+    """A loss function that reaches the operator twice under direct_grads would silently lose the second gradient: the
+    sink hands itself out once and raises on the second take."""
+    from gaus_slam_amd import rasterizer
+    with rasterizer.grad_sink({"means3D": None}):
+        assert rasterizer._take_sink()[0] is not None
+        with pytest.raises(RuntimeError, match="second rasterizer backward"):
+            rasterizer._take_sink()
+    assert rasterizer._take_sink() == (None, None, None)  # outside a context: plain backward
+    with pytest.raises(RuntimeError, match="nested"):
+        with rasterizer.grad_sink({}):
+            with rasterizer.grad_sink({}):
+                pass
