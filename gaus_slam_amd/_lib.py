@@ -10,7 +10,8 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 EXPORTS = ["gs2d_forward", "gs2d_backward", "gs2d_forward_posed", "gs2d_backward_posed", "gs2d_mark_visible", "sknn_dist2", "gs2d_geometry_bytes",
            "gs2d_image_bytes", "gs2d_binning_bytes", "gs2d_geometry_layout", "gs2d_binning_layout",
            "gs2d_image_layout", "gs2d_last_error", "gs2d_build_info", "gs2d_stage_timing_enable",
-           "gs2d_stage_timing_read", "gs2d_slam_loss", "gs2d_adam_step", "gs2d_pose_quat", "gs2d_backward_staged"]
+           "gs2d_stage_timing_read", "gs2d_slam_loss", "gs2d_adam_step", "gs2d_pose_quat", "gs2d_backward_staged", "gs2d_set_deterministic",
+           "gs2d_get_deterministic"]
 
 _lib = None
 
@@ -59,6 +60,8 @@ def lib():
     L.gs2d_slam_loss.argtypes = [i, i, i, vp, vp, vp, vp, f, f, f, f, f, i, i, f, f, f, vp, vp, vp, vp, vp, vp]
     L.gs2d_adam_step.restype = i
     L.gs2d_adam_step.argtypes = [i, vp, vp, f, f, f, i, C.c_ulonglong, vp, vp, vp, vp, vp]
+    L.gs2d_set_deterministic.argtypes = [i]
+    L.gs2d_get_deterministic.restype = i
     L.gs2d_stage_timing_enable.argtypes = [i]
     L.gs2d_stage_timing_read.restype = i
     L.gs2d_stage_timing_read.argtypes = [C.POINTER(C.c_float)]

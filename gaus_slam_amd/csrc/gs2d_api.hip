@@ -8,6 +8,7 @@
 #include <string.h>
 #include <chrono>
 #include <string>
+#include <atomic>
 #include <thread>
 #if defined(__x86_64__) || defined(__i386__)
 #include <immintrin.h>
@@ -82,6 +83,9 @@ struct StageTimer {
 };
 StageTimer g_timer;
 
+// deterministic backward (opt-in, process-wide): must not change between a forward and its backward
+std::atomic<int> g_deterministic{0};
+
 // pinned host word for the num_rendered read-back (one per host thread)
 struct PinnedWord {
     uint32_t* p = nullptr;
@@ -131,11 +135,14 @@ int gs2d_stage_timing_read(float ms[9])
     return 0;
 }
 
+void gs2d_set_deterministic(int on) { g_deterministic.store(on != 0); }
+int gs2d_get_deterministic(void) { return g_deterministic.load(); }
+
 const char* gs2d_build_info(void) { return "gs2d-hip gfx950 strict-fp (fp-contract=off) " __DATE__; }
 
 size_t gs2d_geometry_bytes(int P) { return geom_layout(P).total; }
 size_t gs2d_image_bytes(int width, int height) { return img_layout(width, height).total; }
-size_t gs2d_binning_bytes(int R) { return bin_layout(R).total; }
+size_t gs2d_binning_bytes(int R) { return bin_layout(R, g_deterministic.load() != 0).total; }
 
 void gs2d_geometry_layout(int P, size_t o[5])
 {
@@ -238,7 +245,8 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     if (!img) { (void)wait_total(); return fail_msg("image allocation failed"); }
     const bool same_shape = g_last.P == P && g_last.W == width && g_last.H == height;
     const size_t guess_R = same_shape ? (size_t)g_last.R + g_last.R / 8 + 4096 : (size_t)P * 3 + 4096;
-    const size_t pre_bytes = bin_layout((int)(guess_R > 0x7fffffffull ? 0x7fffffffull : guess_R)).total;
+    const bool det = g_deterministic.load() != 0;
+    const size_t pre_bytes = bin_layout((int)(guess_R > 0x7fffffffull ? 0x7fffffffull : guess_R), det).total;
     char* bin_pre = (char*)binning_alloc(binning_user, pre_bytes);
     if (!wait_total()) return fail_msg("num_rendered read-back failed");
     if (debug) GS2D_CHECK(hipStreamSynchronize(s), "scan");
@@ -248,7 +256,7 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     const int R = (int)num_rendered_u;
 
     g_last.P = P; g_last.W = width; g_last.H = height; g_last.R = num_rendered_u;
-    const BinLayout BL = bin_layout(R);  // offsets always follow the true count; the chunk may be larger than BL.total
+    const BinLayout BL = bin_layout(R, det);  // offsets always follow the true count; the chunk may be larger than BL.total
     char* bin = (bin_pre && BL.total <= pre_bytes) ? bin_pre : (char*)binning_alloc(binning_user, BL.total);
     if (!bin) return fail_msg("binning allocation failed");
     uint32_t* point_list = (uint32_t*)(bin + BL.point_list);
@@ -350,8 +358,9 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
     if (P <= 0) return 0;
     if (g_begin < 0 || g_end > P || g_begin > g_end) return fail_msg("bad Gaussian range");
     if (!geom_buffer || !img_buffer || (R > 0 && !binning_buffer)) return fail_msg("missing forward state");
+    const bool det = g_deterministic.load() != 0;  // the forward sized the binning chunk for it (same flag required)
     const GeomLayout GL = geom_layout(P);
-    const BinLayout BL = bin_layout(R);
+    const BinLayout BL = bin_layout(R, det);
     const ImgLayout IL = img_layout(width, height);
     const float4* rec = (const float4*)(geom_buffer + GL.rec);
     const uint8_t* clamped = (const uint8_t*)(geom_buffer + GL.clamped);
@@ -361,15 +370,30 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
     const uint2* ranges = (const uint2*)(img_buffer + IL.ranges);
     const float* pix_state = (const float*)(img_buffer + IL.pix);
 
-    if ((stages & 1) != 0) {
+    if ((stages & 1) != 0 && !det) {
         GS2D_CHECK(hipMemsetAsync(grad_rec, 0, sizeof(float) * GS2D_GRAD_FLOATS * (size_t)P, s), "memset grad_rec");
         if (R > 0) {
             g_timer.begin(ST_BLEND_BWD, s);
             gs2d::launch_blend_bwd(width, height, ranges, point_list, rec, background, pix_state, hits, dL_dpix, dL_depths,
-                                   grad_rec, use_sa, s);
+                                   grad_rec, use_sa, nullptr, s);
             g_timer.end(ST_BLEND_BWD, s);
             GS2D_STAGE("blend_bwd");
         }
+    }
+    if ((stages & 1) != 0 && det) {
+        // no atomics: per-(instance, quadrant) partial records, then a fixed-order sum per Gaussian (gs2d_det.hip)
+        float* det_slots = (float*)(binning_buffer + BL.det_slots);
+        uint32_t* det_inv = (uint32_t*)(binning_buffer + BL.det_inv);
+        g_timer.begin(ST_BLEND_BWD, s);
+        if (R > 0) {
+            GS2D_CHECK(hipMemsetAsync(det_slots, 0, sizeof(float) * GS2D_GRAD_FLOATS * 4 * (size_t)R, s), "memset det_slots");
+            gs2d::launch_blend_bwd(width, height, ranges, point_list, rec, background, pix_state, hits, dL_dpix, dL_depths,
+                                   grad_rec, use_sa, det_slots, s);
+        }
+        gs2d::launch_det_reduce(P, R, width, height, ranges, point_list, rec, radii, (const uint32_t*)(geom_buffer + GL.tiles_touched),
+                                (const uint32_t*)(geom_buffer + GL.point_offsets), hits, det_inv, det_slots, grad_rec, s);
+        g_timer.end(ST_BLEND_BWD, s);
+        GS2D_STAGE("blend_bwd (deterministic)");
     }
     if ((stages & 2) != 0 && g_end > g_begin) {
         // rasterizer_impl.cu:396-397 + backward.cu:641-642: the backward rebuilds W,H from focal*tan in float32

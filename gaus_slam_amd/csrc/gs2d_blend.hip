@@ -499,22 +499,33 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
 // (row, splat) contribution is first added into LDS (ds_add_f32) and each touched splat of the batch is flushed to its
 // global record ONCE per (quadrant, batch) -- about half as many global atomics, three quarters of a workgroup's LDS
 // budget (29.6 KB, 5 workgroups per CU).
+//
+// DETERMINISTIC variant (DET, opt-in through gs2d_set_deterministic; the reference has none -- its float atomics make
+// gradients run-to-run non-deterministic, backward.cu:441-460): no global atomic at all.  Every (instance, quadrant) pair
+// is accumulated by exactly one wave in exactly one batch, so that wave STORES its 18 sums (the 13 above plus the normal
+// and the low-pass mean2D components) into a slot of its own, det_slots[(instance * 4 + quadrant) * 20 ...], LDS adds are
+// issued row by row (no two lanes of one instruction meet on an address), and det_reduce_kernel sums a Gaussian's slots
+// in a fixed order (its tiles row-major, quadrants 0..3).  Two runs give bit-identical gradients.
 #define GS2D_ACC 13
-struct BwdBatch {
+#define GS2D_ACC_DET 18
+template <int NACC>
+struct BwdBatchT {
     float4 q[4][64];
-    float acc[64 * GS2D_ACC];
+    float acc[64 * NACC];
     uint32_t pn[64];    // list position << 4 | cull bits of the staged splat
     uint8_t ql[4][64];  // per-row queues: slot numbers, deepest first
     uint32_t tail[4];   // the pipeline reads up to two entries past a full queue (values unused)
 };
 
-template <bool USE_SA>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS2D_WAVES_PER_EU, GS2D_WAVES_PER_EU)))
+template <bool USE_SA, bool DET>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DET ? 4 : GS2D_WAVES_PER_EU, DET ? 4 : GS2D_WAVES_PER_EU)))
 blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ pix_state,
                  size_t plane, const uint8_t* __restrict__ hits, const float* __restrict__ dL_dpix,
-                 const float* __restrict__ dL_dothers, float* __restrict__ grad_rec)
+                 const float* __restrict__ dL_dothers, float* __restrict__ grad_rec, float* __restrict__ det_slots)
 {
+    constexpr int NACC = DET ? GS2D_ACC_DET : GS2D_ACC;
+    typedef BwdBatchT<NACC> BwdBatch;
     __shared__ BwdBatch batches[4];
     const int tile = xcd_tile(blockIdx.x, ntiles);
     if (tile < 0) return;
@@ -577,9 +588,10 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     // 0-2 colour | 3-8 Tu,Tv (accumulated as +dk,+dl, the record wants -dk,-dl) | 9-11 Tw | 12-14 normal | 15 opacity
     const int slot = reduce16_row_index(lane);
     const uint32_t slot_sign = (slot >= 3 && slot <= 8) ? 0x80000000u : 0u;
-    const int acc_comp = slot < 12 ? slot : (slot == 15 ? 12 : -1);  // LDS accumulator of this lane's slot; -1: normal (global)
+    // LDS accumulator of this lane's slot; -1: normal component, added straight to the global record (not in DET: 13..15)
+    const int acc_comp = slot < 12 ? slot : (slot == 15 ? 12 : (DET ? slot + 1 : -1));
 #pragma unroll
-    for (int i = 0; i < GS2D_ACC; i++) wb.acc[i * 64 + lane] = 0.f;
+    for (int i = 0; i < NACC; i++) wb.acc[i * 64 + lane] = 0.f;
     // Wave-uniform data-dependent shortcut: when no pixel of this quadrant carries an upstream gradient on the
     // normal channels (SLAM's losses never touch them unless use_normal_loss), everything that only feeds
     // dL_dnormal / the normal term of dL_dalpha is exactly zero and is skipped.  Results are unchanged.
@@ -796,16 +808,24 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                     }                                                                                                 \
                     tot = __uint_as_float(__float_as_uint(tot) ^ slot_sign);                                          \
                     /* LDS float atomics run at a few lanes per clock: rows/components that sum to +-0 skip them */    \
-                    if (acc_comp >= 0 && tot != 0.f) GS2D_EXP_LDSADD(&wb.acc[(J & 63) * GS2D_ACC + acc_comp], tot);   \
+                    if (DET) { /* one row at a time: lanes of different rows may hold the same (splat, component) */ \
+                        _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++)                                              \
+                            if (row == r_ && acc_comp >= 0 && tot != 0.f) atomicAdd(&wb.acc[(J & 63) * NACC + acc_comp], tot); \
+                    } else if (acc_comp >= 0 && tot != 0.f) GS2D_EXP_LDSADD(&wb.acc[(J & 63) * NACC + acc_comp], tot); \
                     else if (ANY_DN && tot != 0.f)                                                                    \
-                        atomicAdd(grad_rec + (size_t)__float_as_uint(cc.w) * GS2D_GRAD_FLOATS + (slot - 9), tot);                                   \
+                        atomicAdd(grad_rec + (size_t)__float_as_uint(cc.w) * GS2D_GRAD_FLOATS + (slot - 9), tot);     \
                     if (__ballot(d_t != 0.f) != 0) {                                                                  \
                         const float g_mx = row_sum_to_lane15(d_t * d0);                                               \
                         const float g_my = row_sum_to_lane15(d_t * d1);                                               \
-                        if (li == 15 && (g_mx != 0.f || g_my != 0.f)) {                                               \
+                        if (DET) {                                                                                    \
+                            _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++)                                          \
+                                if (row == r_ && li == 15 && (g_mx != 0.f || g_my != 0.f)) {                          \
+                                    atomicAdd(&wb.acc[(J & 63) * NACC + 16], g_mx); atomicAdd(&wb.acc[(J & 63) * NACC + 17], g_my); \
+                                }                                                                                     \
+                        } else if (li == 15 && (g_mx != 0.f || g_my != 0.f)) {                                        \
                             float* dst = grad_rec + (size_t)__float_as_uint(cc.w) * GS2D_GRAD_FLOATS;                 \
                             atomicAdd(dst + 16, g_mx); atomicAdd(dst + 17, g_my);                                     \
-                        } \
+                        }                                                                                             \
                     }                                                                                                 \
                 }                                                                                                     \
             }                                                                                                         \
@@ -828,6 +848,22 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
 #endif
         // flush: every touched splat of the batch goes to its global record once, four splats (one per row) per pass
         // two passes (eight splats) per iteration so the LDS round trips of one pass hide behind the other
+        if (DET) {
+            // every staged (instance, quadrant) pair is stored to its own slot, zeros included, exactly once
+            for (int f0 = 64 - fill; f0 < 64; f0 += 4) {
+                const int fa = f0 + row;
+                if (fa < 64) {
+                    float* dst = det_slots + ((size_t)(range.x + (wb.pn[fa] >> 4)) * 4 + wave) * GS2D_GRAD_FLOATS;
+#pragma unroll
+                    for (int c = li; c < NACC; c += 16) {
+                        // accumulator c -> offset in the record: 0-2 colour, 3-11 dT, 12 opacity, 13-15 normal, 16-17 mean2D
+                        const int off = c < 3 ? c : (c < 12 ? c + 3 : (c == 12 ? 15 : (c < 16 ? c - 10 : c)));
+                        dst[off] = wb.acc[fa * NACC + c];
+                        wb.acc[fa * NACC + c] = 0.f;
+                    }
+                }
+            }
+        } else {
         const int flush_off = li < 3 ? li : (li < 12 ? li + 3 : 15);  // accumulator li -> offset in the gradient record
         const bool flush_lane = li < GS2D_ACC;
         for (int f0 = 64 - fill; GS2D_EXP_FLUSH(f0 < 64); f0 += 8) {
@@ -844,6 +880,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                 *pb = 0.f;
                 GS2D_EXP_ATOMIC(atomicAdd(grad_rec + (size_t)idb * GS2D_GRAD_FLOATS + flush_off, vb);)
             }
+        }
         }
     }
     };
@@ -872,17 +909,17 @@ void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_l
 
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
                       const float* bg, const float* pix_state, const uint8_t* hits, const float* dL_dpix,
-                      const float* dL_dothers, float* grad_rec, int use_sa, hipStream_t s)
+                      const float* dL_dothers, float* grad_rec, int use_sa, float* det_slots, hipStream_t s)
 {
     const int gx = (W + GS2D_TILE - 1) / GS2D_TILE, gy = (H + GS2D_TILE - 1) / GS2D_TILE;
     const size_t plane = (size_t)gx * gy * GS2D_TILE_PIX;
     const int grid = GS2D_XCDS * ((gx * gy + GS2D_XCDS - 1) / GS2D_XCDS);
-    if (use_sa)
-        hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(grid), dim3(256), 0, s, W, H, gx, gx * gy, ranges, point_list, rec,
-                           bg, pix_state, plane, hits, dL_dpix, dL_dothers, grad_rec);
-    else
-        hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(grid), dim3(256), 0, s, W, H, gx, gx * gy, ranges, point_list, rec,
-                           bg, pix_state, plane, hits, dL_dpix, dL_dothers, grad_rec);
+#define GS2D_LAUNCH_BWD(SA, DET)                                                                                              \
+    hipLaunchKernelGGL((blend_bwd_kernel<SA, DET>), dim3(grid), dim3(256), 0, s, W, H, gx, gx * gy, ranges, point_list, rec, bg, \
+                       pix_state, plane, hits, dL_dpix, dL_dothers, grad_rec, det_slots)
+    if (det_slots) { if (use_sa) GS2D_LAUNCH_BWD(true, true); else GS2D_LAUNCH_BWD(false, true); }
+    else { if (use_sa) GS2D_LAUNCH_BWD(true, false); else GS2D_LAUNCH_BWD(false, false); }
+#undef GS2D_LAUNCH_BWD
 }
 
 }  // namespace gs2d

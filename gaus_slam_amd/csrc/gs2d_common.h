@@ -33,7 +33,7 @@ struct GeomLayout {
     size_t depths, tiles_touched, point_offsets, rec, clamped, scan_tmp, grad_rec, total;
 };
 struct BinLayout {
-    size_t point_list, hits, keys, vals_alt, keys_alt, hist, total;
+    size_t point_list, hits, keys, vals_alt, keys_alt, hist, det_inv, det_slots, total;
     size_t hist_elems;
 };
 struct ImgLayout {
@@ -66,7 +66,8 @@ static inline GeomLayout geom_layout(int P)
     return L;
 }
 
-static inline BinLayout bin_layout(int R)
+// det: also room for the deterministic backward (inverse permutation + one partial gradient record per (instance, quadrant))
+static inline BinLayout bin_layout(int R, bool det = false)
 {
     BinLayout L;
     size_t o = 0;
@@ -84,6 +85,11 @@ static inline BinLayout bin_layout(int R)
     const size_t cap_elems = L.hist_elems > bin_elems ? L.hist_elems : bin_elems;
     const size_t scan_blk = (cap_elems + GS2D_SCAN_ITEMS - 1) / GS2D_SCAN_ITEMS;
     L.hist = o; o = gs2d_align_up(o + 4 * (cap_elems + scan_blk + 64), 256);
+    L.det_inv = o; L.det_slots = o;
+    if (det) {
+        o = gs2d_align_up(o + 4 * r, 256);
+        L.det_slots = o; o = gs2d_align_up(o + 4 * (size_t)GS2D_GRAD_FLOATS * 4 * r, 256);
+    }
     L.total = o;
     return L;
 }
@@ -157,7 +163,13 @@ void launch_cull(int W, int H, const uint2* ranges, const uint32_t* point_list, 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
                       const float* bg, float* out_color, float* out_others, float* pix_state, const uint8_t* hits, int use_sa,
                       hipStream_t s);
+// det_slots != nullptr selects the deterministic variant: no atomics, per-(instance, quadrant) partial records
+// (GS2D_GRAD_FLOATS floats each, R * 4 of them, zero-initialised by the caller) that launch_det_reduce then sums
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
                       const float* bg, const float* pix_state, const uint8_t* hits, const float* dL_dpix,
-                      const float* dL_dothers, float* grad_rec, int use_sa, hipStream_t s);
+                      const float* dL_dothers, float* grad_rec, int use_sa, float* det_slots, hipStream_t s);
+// deterministic mode: inv[unsorted instance] = sorted position, then grad_rec[g] = sum of g's slots in a fixed order
+void launch_det_reduce(int P, int R, int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
+                       const int* radii, const uint32_t* tiles_touched, const uint32_t* point_offsets, const uint8_t* hits,
+                       uint32_t* inv, const float* det_slots, float* grad_rec, hipStream_t s);
 }  // namespace gs2d

@@ -4,8 +4,12 @@
 // :77 and :218), whose source is NOT vendored in the mounted tree (.gitmodules:1-3).  Semantics restated from
 // its published behaviour: exact 3-NN over all other points (self excluded by index), best[] initialised to
 // FLT_MAX, result (b0+b1+b2)/3.  Algorithm here: 30-bit Morton codes -> radix sort (the rasterizer's own
-// wave64 sort) -> 1024-point boxes with bounds -> per-point search with box pruning.  The result is the exact
-// k-NN set, so it equals a brute-force evaluation bit for bit (squared distances use the same expression order).
+// wave64 sort) -> 64-point boxes with bounds -> one WAVE per box of queries (four independent waves per workgroup, no
+// barrier): the 64 Morton-neighbours of a wave need the same candidate boxes, so the wave selects them once (box-to-box
+// distance against its largest 3-NN radius, 64 boxes tested per step, one per lane), stages each candidate's 64 points
+// in wave-private LDS with one coalesced load and lets every lane scan them as LDS broadcasts behind its own pruning
+// test.  The result is the exact k-NN set, so it equals a brute-force evaluation bit for bit (squared distances use
+// the same expression order; the three smallest distances do not depend on the evaluation order).
 #include "gs2d_common.h"
 #include "../../include/gs2d_rasterizer.h"
 
@@ -13,7 +17,7 @@
 
 namespace {
 
-constexpr int BOX = 1024;
+constexpr int BOX = 64;  // points per box = queries per wave
 
 __device__ __forceinline__ float wave_min(float v)
 {
@@ -106,27 +110,22 @@ gather_kernel(int N, const float* __restrict__ pts, const uint32_t* __restrict__
     sorted[i] = make_float4(pts[3 * (size_t)o], pts[3 * (size_t)o + 1], pts[3 * (size_t)o + 2], 0.f);
 }
 
-__global__ void __launch_bounds__(256) box_bounds_kernel(int N, const float4* __restrict__ sorted, float* __restrict__ boxes)
+// one wave per 64-point box, four boxes per workgroup
+__global__ void __launch_bounds__(256) box_bounds_kernel(int N, const float4* __restrict__ sorted, float* __restrict__ boxes, int nboxes)
 {
-    __shared__ float red[4][6];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= nboxes) return;
+    const int i = b * BOX + lane;
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (int i = b * BOX + threadIdx.x; i < min(N, (b + 1) * BOX); i += 256) {
+    if (i < N) {
         const float4 p = sorted[i];
-        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
-        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+        mn[0] = p.x; mn[1] = p.y; mn[2] = p.z; mx[0] = p.x; mx[1] = p.y; mx[2] = p.z;
     }
-    const int wave = threadIdx.x >> 6;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const float lo = wave_min(mn[a]), hi = wave_max(mx[a]);
-        if ((threadIdx.x & 63) == 0) { red[wave][a] = lo; red[wave][3 + a] = hi; }
+        if (lane == 0) { boxes[6 * b + a] = lo; boxes[6 * b + 3 + a] = hi; }
     }
-    __syncthreads();
-    if (threadIdx.x < 3)
-        boxes[6 * b + threadIdx.x] = fminf(fminf(red[0][threadIdx.x], red[1][threadIdx.x]), fminf(red[2][threadIdx.x], red[3][threadIdx.x]));
-    else if (threadIdx.x < 6)
-        boxes[6 * b + threadIdx.x] = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
 }
 
 __device__ __forceinline__ void update3(const float4 ref, const float4 p, float& b0, float& b1, float& b2)
@@ -141,34 +140,72 @@ __device__ __forceinline__ void update3(const float4 ref, const float4 p, float&
     }
 }
 
+__device__ __forceinline__ float box_dist2(const float4 p, const float* bx)
+{
+    float dist = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float v = a == 0 ? p.x : (a == 1 ? p.y : p.z);
+        const float d = v < bx[a] ? bx[a] - v : (v > bx[3 + a] ? v - bx[3 + a] : 0.f);
+        dist += d * d;
+    }
+    return dist;
+}
+
+// One wave = the 64 consecutive (Morton-sorted) points of one box as queries; waves are independent.
 __global__ void __launch_bounds__(256)
 knn_kernel(int N, const float4* __restrict__ sorted, const uint32_t* __restrict__ order, const float* __restrict__ boxes,
            int nboxes, float* __restrict__ out)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const float4 ref = sorted[i];
+    __shared__ float4 stage[4][BOX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qb = blockIdx.x * 4 + wave;
+    if (qb >= nboxes) return;
+    float4* pts = stage[wave];
+    const int i = qb * BOX + lane;
+    const bool valid = i < N;
+    const float inf = __builtin_inff();
+    const float4 far = make_float4(inf, inf, inf, 0.f);  // padding point: distance +inf, never accepted
+    const float4 ref = valid ? sorted[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
-    for (int j = max(0, i - 3); j <= min(N - 1, i + 3); j++)
-        if (j != i) update3(ref, sorted[j], b0, b1, b2);
-    const float reject = b2;
-    b0 = FLT_MAX; b1 = FLT_MAX; b2 = FLT_MAX;
-    for (int b = 0; b < nboxes; b++) {
-        const float* bx = boxes + 6 * b;
-        float dist = 0.f;
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const float v = a == 0 ? ref.x : (a == 1 ? ref.y : ref.z);
-            const float d = v < bx[a] ? bx[a] - v : (v > bx[3 + a] ? v - bx[3 + a] : 0.f);
-            dist += d * d;
+    // wave-private LDS: operations of one wave execute in order; the fences only stop compiler reordering
+#define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+    // the query box itself
+    pts[lane] = valid ? ref : far;
+    WAVE_LDS_SYNC();
+    for (int j = 0; j < BOX; j++)
+        if (j != lane) update3(ref, pts[j], b0, b1, b2);
+    // largest 3-NN radius among this wave's queries bounds every box that can matter to any of them
+    const float wmax = wave_max(valid ? b2 : 0.f);
+    const float m0 = boxes[6 * qb], m1 = boxes[6 * qb + 1], m2 = boxes[6 * qb + 2];
+    const float M0 = boxes[6 * qb + 3], M1 = boxes[6 * qb + 4], M2 = boxes[6 * qb + 5];
+    for (int base = 0; base < nboxes; base += 64) {
+        const int c = base + lane;
+        bool want = false;
+        if (c < nboxes && c != qb) {
+            const float* bx = boxes + 6 * c;
+            const float d0 = fmaxf(0.f, fmaxf(bx[0] - M0, m0 - bx[3]));
+            const float d1 = fmaxf(0.f, fmaxf(bx[1] - M1, m1 - bx[4]));
+            const float d2 = fmaxf(0.f, fmaxf(bx[2] - M2, m2 - bx[5]));
+            const float dist = (d0 * d0 + d1 * d1) + d2 * d2;  // squared gap between the two boxes
+            // conservative pruning; 0.999999f guards the different rounding of box distances vs point distances
+            want = !(dist * 0.999999f > wmax);
         }
-        // conservative pruning; 0.999999f guards the different rounding of the box distance vs point distances
-        if (dist * 0.999999f > reject || dist * 0.999999f > b2) continue;
-        const int e = min(N, (b + 1) * BOX);
-        for (int j = b * BOX; j < e; j++)
-            if (j != i) update3(ref, sorted[j], b0, b1, b2);
+        uint64_t todo = __ballot(want);
+        while (todo) {
+            const int cb = base + __builtin_ctzll(todo);
+            todo &= todo - 1;
+            WAVE_LDS_SYNC();  // previous candidate fully scanned before pts is overwritten
+            const int j = cb * BOX + lane;
+            pts[lane] = j < N ? sorted[j] : far;
+            WAVE_LDS_SYNC();
+            if (valid && !(box_dist2(ref, boxes + 6 * cb) * 0.999999f > b2))
+                for (int t = 0; t < BOX; t++) update3(ref, pts[t], b0, b1, b2);
+        }
     }
-    out[order[i]] = ((b0 + b1) + b2) / 3.0f;
+#undef WAVE_LDS_SYNC
+    if (valid) out[order[i]] = ((b0 + b1) + b2) / 3.0f;
 }
 
 }  // namespace
@@ -204,7 +241,7 @@ extern "C" int sknn_dist2(int N, const float* points, float* out, gs2d_alloc_fn 
     hipLaunchKernelGGL(morton_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, points, bounds, k_unsorted, v_unsorted);
     gs2d::launch_sort_pairs(N, keys, order, keys_alt, vals_alt, 0, end_bit, hist, BL.hist_elems, s);
     hipLaunchKernelGGL(gather_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, points, order, sorted);
-    hipLaunchKernelGGL(box_bounds_kernel, dim3(nboxes), dim3(256), 0, s, N, sorted, boxes);
-    hipLaunchKernelGGL(knn_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, sorted, order, boxes, nboxes, out);
+    hipLaunchKernelGGL(box_bounds_kernel, dim3((nboxes + 3) / 4), dim3(256), 0, s, N, sorted, boxes, nboxes);
+    hipLaunchKernelGGL(knn_kernel, dim3((nboxes + 3) / 4), dim3(256), 0, s, N, sorted, order, boxes, nboxes, out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

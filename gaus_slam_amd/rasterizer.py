@@ -242,6 +242,16 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
 
 
+def set_deterministic(on=True):
+    """Opt-in deterministic backward (gs2d_set_deterministic): no float atomics, gradients bit-identical from run to run.
+    Process-wide; keep it unchanged between a forward and its backward."""
+    _lib.lib().gs2d_set_deterministic(int(bool(on)))
+
+
+def is_deterministic():
+    return bool(_lib.lib().gs2d_get_deterministic())
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     """_C.mark_visible (rasterize_points.cu:241-260)."""
     L = _lib.lib()

@@ -162,6 +162,17 @@ int gs2d_backward_staged(
     float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot, int use_sa, int debug, const float* pose_Rt,
     const float* pose_quat, float* dL_dpose /* [12] */, void* stream);
 
+/*
+ * Deterministic backward (opt-in, process-wide; off by default).  The reference accumulates per-Gaussian gradients with
+ * float atomics (backward.cu:343,396,441-460), so its gradients differ from run to run in the last bits, and so do this
+ * library's by default.  With the switch on, the backward uses no atomics: every (instance, quadrant) pair is summed by
+ * one wave into a record of its own and a Gaussian's records are added in a fixed order -- two runs on the same inputs give
+ * bit-identical gradients (tests/test_gpu_round2.py).  Slower (about 2x for the backward) and 324 B more scratch per tile
+ * instance.  The switch must not change between a forward and its backward: the forward sizes the binning chunk for it.
+ */
+void gs2d_set_deterministic(int on);
+int gs2d_get_deterministic(void);
+
 /* present: [P] bytes (0/1). */
 int gs2d_mark_visible(int P, const float* means3D, const float* viewmatrix,
                       const float* projmatrix, uint8_t* present, void* stream);

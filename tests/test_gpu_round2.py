@@ -141,3 +141,41 @@ def test_backward_runs_without_a_forward_on_the_same_stream_state(oracle):
     for k in ["dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations"]:
         assert util.grad_err(g1[k], go[k].reshape(g1[k].shape)) <= GRAD_TOL, k
         assert util.grad_err(g2[k], g1[k]) <= 1e-5, k  # float atomics: equal up to summation order
+
+
+@pytest.mark.parametrize("P,W,H,channels", [(8000, 256, 192, (0, 1, 2, 3, 4, 5, 6)), (150000, 640, 480, (0, 1, 5, 6))])
+def test_deterministic_backward_is_bit_identical(oracle, P, W, H, channels):
+    """Opt-in deterministic backward (gs2d_set_deterministic; SURVEY.md section 5: the reference's float atomics,
+    backward.cu:441-460, make its gradients run-to-run non-deterministic): repeated backwards -- also from a second,
+    independent forward -- give bit-identical gradients, which still match the oracle; the default (atomic) mode agrees
+    with them to summation-order accuracy."""
+    from gaus_slam_amd import rasterizer
+    keys = ["dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dtransMat", "dL_dmeans2D"]
+    sc = util.make_scene(P, W, H, seed=51, regime="mapping")
+    sc["scales"][: P // 50] *= 0.02  # sub-pixel splats: the low-pass (mean2D) branch of the backward
+    oracle.set_threads(os.cpu_count() or 1)
+    o = util.oracle_forward(oracle, sc, use_sa=True)
+    stable = (o["stability"] > KNIFE).reshape(H, W)
+    dc, da = util.make_upstream_grads(W, H, channels=channels)
+    dc, da = (dc * W * H).numpy(), (da * W * H).numpy()
+    dc[:, ~stable] = 0; da[:, ~stable] = 0
+    go = oracle.backward(o, dc, da)
+    oracle.set_threads(1)
+    assert not rasterizer.is_deterministic()
+    h0 = util.hip_forward(sc, use_sa=True)
+    g_atomic = util.hip_backward(h0, dc, da)
+    rasterizer.set_deterministic(True)
+    try:
+        h1 = util.hip_forward(sc, use_sa=True)
+        g1 = util.hip_backward(h1, dc, da)
+        g2 = util.hip_backward(h1, dc, da)
+        h2 = util.hip_forward(sc, use_sa=True)
+        g3 = util.hip_backward(h2, dc, da)
+    finally:
+        rasterizer.set_deterministic(False)
+    for k in keys:
+        assert np.array_equal(g1[k].view(np.uint32), g2[k].view(np.uint32)), k
+        assert np.array_equal(g1[k].view(np.uint32), g3[k].view(np.uint32)), k
+        assert util.grad_err(g1[k], go[k].reshape(g1[k].shape)) <= GRAD_TOL, k
+        assert util.grad_err(g_atomic[k], g1[k]) <= 1e-5, k
+    assert np.abs(g1["dL_dmeans2D"]).max() > 0
