@@ -89,7 +89,8 @@ def main():
                     "the multi-rank path on a single GPU)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--keyframes-per-gpu", type=int, default=1, help="keyframes each rank renders per step (default 1 = the "
-                    "headline metric; >1 uses two HIP streams per rank, see ba_shard.KeyframeShardedBA)")
+                    "headline metric); rendered one after the other unless --streams 2")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams a rank spreads its keyframes over (ba_shard.KeyframeShardedBA)")
     ap.add_argument("--json-out", default=None, help="also write the JSON line to this file (profiles/...)")
     args = ap.parse_args()
 
@@ -191,7 +192,7 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
         return (pkg["render_color"], pkg["allmap"]), (dcolor, dallmap)
 
     # gradients are produced directly in the all-reduce bucket whenever the bucket is consumed (N > 1, fused Adam)
-    ba = ba_shard.KeyframeShardedBA(params, render_fn, direct_grads=(world > 1 or args.adam == "fused"))
+    ba = ba_shard.KeyframeShardedBA(params, render_fn, direct_grads=(world > 1 or args.adam == "fused"), streams=args.streams)
     kpg = max(1, args.keyframes_per_gpu)
     keyframes = list(range(world * kpg))  # keyframe i goes to rank i % world
     opt = None
@@ -307,7 +308,7 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"synthetic {W}x{H} / {P} Gaussians ({args.workload}; BASELINE.md section 2), {regime} regime, "
-                               f"use_sa={use_sa}, {kpg} keyframe{'s' if kpg > 1 else ''} per GPU" + (" on two HIP streams" if kpg > 1 else ""), "num_rendered": R, "visible": visible,
+                               f"use_sa={use_sa}, {kpg} keyframe{'s' if kpg > 1 else ''} per GPU" + (f" on {args.streams} HIP streams" if kpg > 1 and args.streams > 1 else ""), "num_rendered": R, "visible": visible,
                    "step": "op forward+backward" + (" + all-reduce of the [P,13] grad bucket" if world > 1 else "")
                            + (f" + {args.adam} Adam (lr=0)" if args.adam else ""),
                    "parallelism": f"keyframe-sharded x{world}", "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4)},

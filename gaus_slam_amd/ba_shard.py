@@ -83,7 +83,7 @@ class KeyframeShardedBA:
     render_loss_fn(params, keyframe) -> scalar loss OR (outputs, upstream_grads) pair for torch.autograd.backward.
     """
 
-    def __init__(self, params, render_loss_fn, group=None, average=False, direct_grads=False, streams=2, overlap_chunks=4):
+    def __init__(self, params, render_loss_fn, group=None, average=False, direct_grads=False, streams=1, overlap_chunks=4):
         """direct_grads: let the rasterizer's backward write the parameter gradients straight into the bucket (no pack
         copies).  Safe in every case -- a gradient that did not land in the bucket (the op was not fed the leaf itself,
         e.g. activations in between) is packed by copy as before.
@@ -92,9 +92,12 @@ class KeyframeShardedBA:
         (SURVEY.md section 8(e)); 1 = one all-reduce of the whole bucket after the backward."""
         self.direct_grads = direct_grads
         self.overlap_chunks = max(1, int(overlap_chunks))
-        # A rank that holds several keyframes of the batch renders them on `streams` HIP streams (forwards first, then
-        # backwards): at 640x480 one frame has 4800 quadrant-waves for 1024 SIMDs, so the kernels of a second frame
-        # fill the idle tails and the latency-bound binning stages of the first (measured: 1.34 vs 1.52 ms per pair).
+        self._overlap_ok = False  # set once a chunked reduction has completed
+        # A rank that holds several keyframes of the batch renders them one after the other (streams=1).  streams=2 renders
+        # them on two HIP streams (forwards first, then backwards): in round 1 a second frame's kernels filled the idle
+        # tails of the first (1.34 vs 1.52 ms per pair); since the blend kernels keep the waves of a SIMD together by issue
+        # priority there is no tail left to fill and two concurrent frames only fight for the SIMDs (round 2: 1.46 ms per
+        # pair on two streams vs 1.25 ms sequentially, profiles/bench_r02_kpg2*.json).
         self.n_streams = max(1, int(streams))
         self._streams = None
         self.params = params
@@ -172,6 +175,30 @@ class KeyframeShardedBA:
             cur.wait_stream(st)
         return out
 
+    def _step_overlapped(self, keyframe, P):
+        """One keyframe on this rank, gradients written into the bucket, per-chunk all-reduce overlapped with the backward."""
+        rows = -(-P // self.overlap_chunks)
+        done = []
+
+        def on_chunk(g0, g1):
+            done.append((g0, g1))
+            self.bucket.reduce_rows(g0, g1, self.group)
+        g = self.local_backward(keyframe, self.bucket.views, chunk_rows=rows, on_chunk=on_chunk)
+        stale = [n for n, v in self.bucket.views.items() if g.get(n) is None or g[n].data_ptr() != v.data_ptr()]
+        if not done:  # the operator was not reached with the leaves themselves: nothing has been reduced yet
+            self.bucket.pack(g)
+            self.bucket.all_reduce(self.group, self.average)
+            return self.bucket.views
+        self.bucket.wait(self.group, self.average)
+        self._overlap_ok = True
+        for n in stale:  # a gradient that did not land in the bucket: copy it in and reduce that field on its own
+            v = self.bucket.views[n]
+            v.copy_(g[n].reshape(v.shape)) if g.get(n) is not None else v.zero_()
+            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+            if self.average:
+                v.div_(self.world_size)
+        return self.bucket.views
+
     def step(self, keyframes):
         """One BA step over a batch of keyframes (len == world_size in the bench; ragged batches allowed: ranks
         without a keyframe contribute zeros).  Returns the reduced bucket views (name -> [P,k])."""
@@ -185,26 +212,17 @@ class KeyframeShardedBA:
         # Chunked, overlapped reduction: decided from GLOBAL facts only (every rank must issue the same collectives):
         # exactly one keyframe per rank, gradients written straight into the bucket.
         if self.direct_grads and self.overlap_chunks > 1 and len(keyframes) == self.world_size and self.params["means3D"].is_cuda:
-            rows = -(-P // self.overlap_chunks)
-            done = []
-
-            def on_chunk(g0, g1):
-                done.append((g0, g1))
-                self.bucket.reduce_rows(g0, g1, self.group)
-            g = self.local_backward(mine[0], self.bucket.views, chunk_rows=rows, on_chunk=on_chunk)
-            stale = [n for n, v in self.bucket.views.items() if g.get(n) is None or g[n].data_ptr() != v.data_ptr()]
-            if not done:  # the operator was not reached with the leaves themselves: nothing has been reduced yet
-                self.bucket.pack(g)
-                self.bucket.all_reduce(self.group, self.average)
-                return self.bucket.views
-            self.bucket.wait(self.group, self.average)
-            for n in stale:  # a gradient that did not land in the bucket: copy it in and reduce that field on its own
-                v = self.bucket.views[n]
-                v.copy_(g[n].reshape(v.shape)) if g.get(n) is not None else v.zero_()
-                dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
-                if self.average:
-                    v.div_(self.world_size)
-            return self.bucket.views
+            try:
+                return self._step_overlapped(mine[0], P)
+            except Exception as ex:  # noqa: BLE001
+                # The coalesced asynchronous collective is torch-internal API (dist._coalescing_manager).  Should this torch
+                # build reject it, the failure is the same on every rank and happens before anything was communicated in this
+                # step: fall back, permanently, to one all-reduce of the whole bucket after the backward.
+                if self._overlap_ok or self.bucket._pending:
+                    raise
+                import warnings
+                warnings.warn(f"overlapped chunk all-reduce unavailable ({type(ex).__name__}: {ex}); using one all-reduce per step")
+                self.overlap_chunks = 1
         if not mine:
             self.bucket.flat.zero_()
         elif len(mine) > 1 and self.n_streams > 1 and self.params["means3D"].is_cuda:

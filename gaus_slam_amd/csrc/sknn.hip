@@ -53,6 +53,7 @@ __global__ void __launch_bounds__(256) bounds_init_kernel(uint32_t* b)
 
 __global__ void __launch_bounds__(256) bounds_kernel(int N, const float* __restrict__ pts, uint32_t* __restrict__ b)
 {
+    __shared__ float red[4][6];
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256)
 #pragma unroll
@@ -64,11 +65,14 @@ __global__ void __launch_bounds__(256) bounds_kernel(int N, const float* __restr
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const float lo = wave_min(mn[a]), hi = wave_max(mx[a]);
-        if ((threadIdx.x & 63) == 0) {
-            atomicMin(&b[a], enc(lo));
-            atomicMax(&b[3 + a], enc(hi));
-        }
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][a] = lo; red[threadIdx.x >> 6][3 + a] = hi; }
     }
+    __syncthreads();
+    // six atomics per WORKGROUP on the six result words (one per wave saturated them: ~90 atomics/us on one address)
+    if (threadIdx.x < 3)
+        atomicMin(&b[threadIdx.x], enc(fminf(fminf(red[0][threadIdx.x], red[1][threadIdx.x]), fminf(red[2][threadIdx.x], red[3][threadIdx.x]))));
+    else if (threadIdx.x < 6)
+        atomicMax(&b[threadIdx.x], enc(fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]))));
 }
 
 __device__ __forceinline__ uint32_t spread10(uint32_t x)
@@ -110,8 +114,12 @@ gather_kernel(int N, const float* __restrict__ pts, const uint32_t* __restrict__
     sorted[i] = make_float4(pts[3 * (size_t)o], pts[3 * (size_t)o + 1], pts[3 * (size_t)o + 2], 0.f);
 }
 
-// one wave per 64-point box, four boxes per workgroup
-__global__ void __launch_bounds__(256) box_bounds_kernel(int N, const float4* __restrict__ sorted, float* __restrict__ boxes, int nboxes)
+// one wave per 64-point box, four boxes per workgroup.  boxes[b] = the box's AABB; sub[b][s] = AABB of its s-th run of 8
+// consecutive points: 64 Morton-consecutive points sometimes straddle a jump of the curve and then have a huge AABB that
+// prunes nothing, their runs of 8 are (almost) always compact.
+constexpr int SUB = 8;
+__global__ void __launch_bounds__(256)
+box_bounds_kernel(int N, const float4* __restrict__ sorted, float* __restrict__ boxes, float* __restrict__ sub, int nboxes)
 {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= nboxes) return;
@@ -123,7 +131,14 @@ __global__ void __launch_bounds__(256) box_bounds_kernel(int N, const float4* __
     }
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const float lo = wave_min(mn[a]), hi = wave_max(mx[a]);
+        float lo = mn[a], hi = mx[a];
+#pragma unroll
+        for (int d = 1; d < SUB; d <<= 1) { lo = fminf(lo, __shfl_xor(lo, d, 64)); hi = fmaxf(hi, __shfl_xor(hi, d, 64)); }
+        if ((lane & (SUB - 1)) == 0) {
+            float* sb = sub + ((size_t)b * (BOX / SUB) + lane / SUB) * 6;
+            sb[a] = lo; sb[3 + a] = hi;  // an empty run keeps (+max, -max): its distance test is never passed
+        }
+        lo = wave_min(mn[a]); hi = wave_max(mx[a]);
         if (lane == 0) { boxes[6 * b + a] = lo; boxes[6 * b + 3 + a] = hi; }
     }
 }
@@ -155,7 +170,7 @@ __device__ __forceinline__ float box_dist2(const float4 p, const float* bx)
 // One wave = the 64 consecutive (Morton-sorted) points of one box as queries; waves are independent.
 __global__ void __launch_bounds__(256)
 knn_kernel(int N, const float4* __restrict__ sorted, const uint32_t* __restrict__ order, const float* __restrict__ boxes,
-           int nboxes, float* __restrict__ out)
+           const float* __restrict__ sub, int nboxes, float* __restrict__ out)
 {
     __shared__ float4 stage[4][BOX];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -176,32 +191,64 @@ knn_kernel(int N, const float4* __restrict__ sorted, const uint32_t* __restrict_
     WAVE_LDS_SYNC();
     for (int j = 0; j < BOX; j++)
         if (j != lane) update3(ref, pts[j], b0, b1, b2);
-    // largest 3-NN radius among this wave's queries bounds every box that can matter to any of them
-    const float wmax = wave_max(valid ? b2 : 0.f);
-    const float m0 = boxes[6 * qb], m1 = boxes[6 * qb + 1], m2 = boxes[6 * qb + 2];
-    const float M0 = boxes[6 * qb + 3], M1 = boxes[6 * qb + 4], M2 = boxes[6 * qb + 5];
+    // Candidate boxes are selected per RUN of 8 queries, not for the whole wave: a box that straddles a jump of the Morton
+    // curve has a huge AABB whose gap to almost every other box is 0 (one such wave walked 1700 candidates and the kernel
+    // waited for it), its runs of 8 are compact.  qsub[r] = (AABB of run r, largest 3-NN radius among its queries).
+    __shared__ float qsub_all[4][BOX / SUB][8];
+    float (*qsub)[8] = qsub_all[wave];
+    {
+        float rmax = valid ? b2 : 0.f;
+#pragma unroll
+        for (int d = 1; d < SUB; d <<= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, d, 64));
+        if ((lane & (SUB - 1)) == 0) {
+            const float* sb = sub + ((size_t)qb * (BOX / SUB) + lane / SUB) * 6;
+#pragma unroll
+            for (int a = 0; a < 6; a++) qsub[lane / SUB][a] = sb[a];
+            qsub[lane / SUB][6] = rmax;
+        }
+    }
+    WAVE_LDS_SYNC();
     for (int base = 0; base < nboxes; base += 64) {
         const int c = base + lane;
         bool want = false;
         if (c < nboxes && c != qb) {
             const float* bx = boxes + 6 * c;
-            const float d0 = fmaxf(0.f, fmaxf(bx[0] - M0, m0 - bx[3]));
-            const float d1 = fmaxf(0.f, fmaxf(bx[1] - M1, m1 - bx[4]));
-            const float d2 = fmaxf(0.f, fmaxf(bx[2] - M2, m2 - bx[5]));
-            const float dist = (d0 * d0 + d1 * d1) + d2 * d2;  // squared gap between the two boxes
-            // conservative pruning; 0.999999f guards the different rounding of box distances vs point distances
-            want = !(dist * 0.999999f > wmax);
+            const float c0 = bx[0], c1 = bx[1], c2 = bx[2], C0 = bx[3], C1 = bx[4], C2 = bx[5];
+#pragma unroll
+            for (int r = 0; r < BOX / SUB; r++) {
+                const float d0 = fmaxf(0.f, fmaxf(c0 - qsub[r][3], qsub[r][0] - C0));
+                const float d1 = fmaxf(0.f, fmaxf(c1 - qsub[r][4], qsub[r][1] - C1));
+                const float d2 = fmaxf(0.f, fmaxf(c2 - qsub[r][5], qsub[r][2] - C2));
+                const float dist = (d0 * d0 + d1 * d1) + d2 * d2;  // squared gap between run r and the candidate box
+                // conservative pruning; 0.999999f guards the different rounding of box distances vs point distances
+                // (an empty run has an inverted AABB: infinite gap, never wanted)
+                want = want || !(dist * 0.999999f > qsub[r][6]);
+            }
         }
         uint64_t todo = __ballot(want);
+        // the next candidate's points are fetched while the current one is scanned
+        int cb = todo ? base + __builtin_ctzll(todo) : 0;
+        float4 nextp = far;
+        if (todo) { const int j = cb * BOX + lane; if (j < N) nextp = sorted[j]; }
         while (todo) {
-            const int cb = base + __builtin_ctzll(todo);
             todo &= todo - 1;
+            const int cur = cb;
             WAVE_LDS_SYNC();  // previous candidate fully scanned before pts is overwritten
-            const int j = cb * BOX + lane;
-            pts[lane] = j < N ? sorted[j] : far;
+            pts[lane] = nextp;
             WAVE_LDS_SYNC();
-            if (valid && !(box_dist2(ref, boxes + 6 * cb) * 0.999999f > b2))
-                for (int t = 0; t < BOX; t++) update3(ref, pts[t], b0, b1, b2);
+            if (todo) {
+                cb = base + __builtin_ctzll(todo);
+                const int j = cb * BOX + lane;
+                nextp = j < N ? sorted[j] : far;
+            }
+            if (valid && !(box_dist2(ref, boxes + 6 * cur) * 0.999999f > b2)) {
+                const float* sb = sub + (size_t)cur * (BOX / SUB) * 6;
+                for (int r = 0; r < BOX / SUB; r++) {  // run by run: a straddling box is pruned piecewise
+                    if (box_dist2(ref, sb + 6 * r) * 0.999999f > b2) continue;
+#pragma unroll
+                    for (int t = 0; t < SUB; t++) update3(ref, pts[r * SUB + t], b0, b1, b2);
+                }
+            }
         }
     }
 #undef WAVE_LDS_SYNC
@@ -220,6 +267,7 @@ extern "C" int sknn_dist2(int N, const float* points, float* out, gs2d_alloc_fn 
     size_t o = BL.total;
     const size_t off_sorted = o; o = gs2d_align_up(o + sizeof(float4) * (size_t)N, 256);
     const size_t off_boxes = o; o = gs2d_align_up(o + sizeof(float) * 6 * (size_t)nboxes, 256);
+    const size_t off_sub = o; o = gs2d_align_up(o + sizeof(float) * 6 * (BOX / SUB) * (size_t)nboxes, 256);
     const size_t off_bounds = o; o = gs2d_align_up(o + 64, 256);
     char* ws = (char*)ws_alloc(ws_user, o);
     if (!ws) return -1;
@@ -230,10 +278,11 @@ extern "C" int sknn_dist2(int N, const float* points, float* out, gs2d_alloc_fn 
     uint32_t* hist = (uint32_t*)(ws + BL.hist);
     float4* sorted = (float4*)(ws + off_sorted);
     float* boxes = (float*)(ws + off_boxes);
+    float* sub = (float*)(ws + off_sub);
     uint32_t* bounds = (uint32_t*)(ws + off_bounds);
 
     hipLaunchKernelGGL(bounds_init_kernel, dim3(1), dim3(256), 0, s, bounds);
-    const int rb = min(1024, (N + 255) / 256);
+    const int rb = min(256, (N + 255) / 256);
     hipLaunchKernelGGL(bounds_kernel, dim3(rb), dim3(256), 0, s, N, points, bounds);
     const int end_bit = 30, passes = (end_bit + 7) / 8;
     uint64_t* k_unsorted = (passes & 1) ? keys_alt : keys;
@@ -241,7 +290,7 @@ extern "C" int sknn_dist2(int N, const float* points, float* out, gs2d_alloc_fn 
     hipLaunchKernelGGL(morton_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, points, bounds, k_unsorted, v_unsorted);
     gs2d::launch_sort_pairs(N, keys, order, keys_alt, vals_alt, 0, end_bit, hist, BL.hist_elems, s);
     hipLaunchKernelGGL(gather_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, points, order, sorted);
-    hipLaunchKernelGGL(box_bounds_kernel, dim3((nboxes + 3) / 4), dim3(256), 0, s, N, sorted, boxes, nboxes);
-    hipLaunchKernelGGL(knn_kernel, dim3((nboxes + 3) / 4), dim3(256), 0, s, N, sorted, order, boxes, nboxes, out);
+    hipLaunchKernelGGL(box_bounds_kernel, dim3((nboxes + 3) / 4), dim3(256), 0, s, N, sorted, boxes, sub, nboxes);
+    hipLaunchKernelGGL(knn_kernel, dim3((nboxes + 3) / 4), dim3(256), 0, s, N, sorted, order, boxes, sub, nboxes, out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

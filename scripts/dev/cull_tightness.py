@@ -1,0 +1,29 @@
+"""Dev: how tight is the sub-block cull?  Compares the library's 16 cull bits per instance (read back from the binning
+chunk) with the exact bits (any pixel of the sub-block passes the alpha test, brute force on the CPU) on the bench scene.
+Needs scripts/dev/exact_bits.so: gcc -O2 -fopenmp -shared -fPIC scripts/dev/exact_bits.c -o scripts/dev/exact_bits.so -lm"""
+import ctypes as C, sys, json
+import numpy as np
+sys.path.insert(0, ".")
+import torch
+from tests import util
+from oracle import gs2d_oracle as orc
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
+W, H = 640, 480
+orc.set_threads(64)
+sc = util.make_scene(P, W, H, seed=0, regime="mapping")
+o = util.oracle_forward(orc, sc, use_sa=True)
+h = util.hip_forward(sc, use_sa=True)
+R = h["num_rendered"]
+binning = h["buffers"][1].cpu().numpy()
+off = ((4 * R + 255) // 256) * 256  # BinLayout: point_list, then hits
+hits = np.frombuffer(binning.tobytes()[off:off + 4 * R], dtype=np.uint32)
+L = C.CDLL("scripts/dev/exact_bits.so")
+ex = np.zeros(R, np.uint32)
+p = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+keep = [np.ascontiguousarray(o[k]) for k in ("ranges", "point_list", "means2D", "transMats", "normal_opacity")]
+L.exact_bits(W, H, *[p(a) for a in keep], p(ex))
+pc = lambda a: int(np.unpackbits(a.view(np.uint8)).sum())
+missed = int(np.count_nonzero(ex & ~hits))
+print(json.dumps({"instances": R, "exact_row_pairs": pc(ex), "cull_row_pairs": pc(hits), "looseness": round(pc(hits) / pc(ex), 4),
+                  "instances_exact_nonzero": int(np.count_nonzero(ex)), "instances_cull_nonzero": int(np.count_nonzero(hits)),
+                  "exact_bits_missed_by_cull": missed}))

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Instruction-mix table of the blend kernels from the compiler's ISA (hipcc -S with the product flags): VALU / SALU /
+LDS / VMEM / waitcnt / nop per loop TRIP (one unrolled step of the software-pipelined trip loop), per staged CHUNK
+(staging loop body) and per FLUSH pass (backward only), for the shipped source.  Output kept as profiles/isa_mix_rNN.txt.
+
+Regions are located by anchors in the linear ISA: a trip step is the code between two consecutive queue reads
+(`ds_read_u8`) more than 40 instructions apart; the staging chunk is the loop body around the cull-bit byte load
+(`global_load_ubyte`); a flush pass is the loop body containing the gradient-record atomics (`global_atomic_add_f32`
+after the last trip step).  usage: isa_mix.py [path/to/gs2d_blend.hip]"""
+import collections
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gaus_slam_amd", "csrc", "gs2d_blend.hip")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17"]
+
+
+def classify(op):
+    if op.startswith("s_waitcnt"):
+        return "waitcnt"
+    if op.startswith("s_nop"):
+        return "nop"
+    if op.startswith(("s_cbranch", "s_branch")):
+        return "branch"
+    if op.startswith("s_"):
+        return "SALU"
+    if op.startswith("ds_"):
+        return "LDS"
+    if op.startswith(("global_", "buffer_", "scratch_", "flat_")):
+        return "VMEM"
+    if op.startswith(("v_exp", "v_rcp", "v_sqrt", "v_rsq", "v_log")):
+        return "VALU-trans"
+    if op.startswith("v_"):
+        return "VALU"
+    return "other"
+
+
+def mix(seg):
+    c = collections.Counter(classify(o) for o in seg)
+    c["VALU"] += c.pop("VALU-trans", 0) * 0  # keep transcendental count separately, also count them as VALU below
+    return c
+
+
+def fmt(name, seg):
+    c = collections.Counter(classify(o) for o in seg)
+    valu = c["VALU"] + c["VALU-trans"]
+    return (f"  {name:34s} instr {len(seg):4d} | VALU {valu:4d} (transcendental {c['VALU-trans']:2d}) | SALU {c['SALU']:3d} | "
+            f"branch {c['branch']:2d} | LDS {c['LDS']:2d} | VMEM {c['VMEM']:2d} | s_waitcnt {c['waitcnt']:2d} | s_nop {c['nop']:2d}")
+
+
+def loop_body_around(ops, labels, idx):
+    """Innermost [label ... backward branch] range containing instruction idx."""
+    best = None
+    for i, (op, arg) in enumerate(ops):
+        if op.startswith(("s_cbranch", "s_branch")) and arg in labels and labels[arg] <= idx <= i:
+            if best is None or (i - labels[arg]) < (best[1] - best[0]):
+                best = (labels[arg], i)
+    return best
+
+
+def main():
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "blend.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-S", "--cuda-device-only", "-o", out, SRC],
+                              stderr=subprocess.DEVNULL)
+        src = open(out).read()
+    print(f"# ISA instruction mix of {os.path.relpath(SRC, ROOT)} (hipcc {' '.join(FLAGS)})")
+    for kname, title in (("blend_fwd_kernelILb1E", "blend_fwd_kernel<USE_SA=true>"),
+                         ("blend_bwd_kernelILb1ELb0E", "blend_bwd_kernel<USE_SA=true, DET=false>")):
+        m = re.search(r"\n(_ZN\S*" + kname + r"\S*):[^\n]*\n(.*?)s_endpgm", src, re.S)
+        body = m.group(2)
+        ops, labels = [], {}
+        for line in body.split("\n"):
+            t = line.split(";")[0].strip()
+            if not t:
+                continue
+            if t.endswith(":") and t.startswith(".LBB"):
+                labels[t[:-1]] = len(ops)
+                continue
+            if re.match(r"^[a-z_0-9]+(\s|$)", t) and not t.startswith("."):
+                parts = t.split()
+                ops.append((parts[0], parts[-1] if len(parts) > 1 else ""))
+        names = [o for o, _ in ops]
+        vg = re.search(r"\.vgpr_count:\s+(\d+)", src[m.end():m.end() + 6000])
+        print(f"\n{title}: {len(ops)} instructions in the kernel" + (f", {vg.group(1)} VGPRs" if vg else ""))
+        q = [i for i, o in enumerate(names) if o == "ds_read_u8"]
+        # the body without normal-channel gradients comes last in the backward; the forward has one body.  Each body has
+        # two prologue queue reads and one per unrolled step: step A = [read A, read B), step B = [read B, back edge]
+        rA, rB = q[-2], q[-1]
+        back = None
+        for i in range(rB, len(ops)):
+            op, arg = ops[i]
+            if op.startswith(("s_cbranch", "s_branch")) and arg in labels and labels[arg] <= rA:
+                back = i
+                break
+        if "bwd" in kname:  # one LDS accumulate per step: the cleanest anchor of the backward's two unrolled steps
+            da = [i for i, o in enumerate(names) if o == "ds_add_f32"]
+            print(fmt("trip step (between LDS accumulates)", names[da[-2]:da[-1]]))
+        else:
+            print(fmt("trip step A", names[rA:rB]))
+            print(fmt("trip step B", names[rB:(back + 1 if back else rB)]))
+        hb = [i for i, o in enumerate(names) if o == "global_load_ubyte" and i < rA]
+        stage = loop_body_around(ops, labels, hb[-1]) if hb else None
+        if stage:
+            print(fmt("staging loop body (64-instance chunk)", names[stage[0]:stage[1] + 1]))
+        # the batch loop: innermost loop containing both the staging body and the trip steps
+        batch = None
+        for i, (op, arg) in enumerate(ops):
+            if op.startswith(("s_cbranch", "s_branch")) and arg in labels and stage and labels[arg] <= stage[0] and i >= (back or rB):
+                if batch is None or (i - labels[arg]) < (batch[1] - batch[0]):
+                    batch = (labels[arg], i)
+        if batch and stage and back:
+            rest = names[batch[0]:stage[0]] + names[stage[1] + 1:rA] + names[back + 1:batch[1] + 1]
+            if "bwd" not in kname:
+                print(fmt("rest of a batch (queues, prologue)", rest))
+
+if __name__ == "__main__":
+    main()

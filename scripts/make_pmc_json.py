@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Turns a profiling directory made by scripts/gpu_round2_artifacts.sh (rocprofv3 PMC passes of `bench.py`) into the two
+small JSON files bench.py reads: pmc_traffic (HBM bytes per launch per stage, FETCH_SIZE doubled as the gfx950 guide
+prescribes) and pmc_valu (SQ_INSTS_VALU / SQ_INSTS_SALU per launch of the blend kernels).  usage: make_pmc_json.py <dir>"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+d = sys.argv[1]
+STAGE = {"blend_fwd_kernel": "blend_fwd", "blend_bwd_kernel": "blend_bwd", "cull_kernel": "cull", "preprocess_fwd_kernel": "preprocess",
+         "preprocess_bwd_kernel": "preprocess_bwd", "bin_hist_kernel": "sort", "bin_scatter_kernel": "sort", "tile_depth_sort_kernel": "sort",
+         "scan_reduce_kernel": "sort", "scan_apply_kernel": "sort", "duplicate_kernel": "duplicate"}
+
+
+def counters(sub):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            for k in STAGE:
+                if k in r["Kernel_Name"]:
+                    acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+
+
+fe, wr, sq, sq2 = counters("pmc_fetch"), counters("pmc_write"), counters("sq"), counters("sq2")
+traffic = collections.defaultdict(float)
+for k, st in STAGE.items():
+    f = fe.get(k, {}).get("FETCH_SIZE", 0.0)
+    w = wr.get(k, {}).get("WRITE_SIZE", 0.0)
+    traffic[st] += (2 * f + w) * 1024  # KB as reported -> bytes; FETCH_SIZE counts 64 B per 128-B request on gfx950
+out_t = {k: int(v) for k, v in traffic.items()}
+out_t["_note"] = ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes of `bench.py --steps 3`), "
+                  "FETCH_SIZE doubled per the gfx950 guide (MI355X_MICROARCH.md, HBM); sort = bin_hist + scans + bin_scatter + tile_depth_sort")
+out_v = {}
+for k in ("blend_fwd_kernel", "blend_bwd_kernel", "cull_kernel"):
+    if k in sq:
+        out_v[STAGE[k]] = {"valu_wave_insts": int(sq[k].get("SQ_INSTS_VALU", 0)), "salu_wave_insts": int(sq[k].get("SQ_INSTS_SALU", 0)),
+                           "wave_quad_cycles": int(sq[k].get("SQ_WAVE_CYCLES", 0)), "wait_any": int(sq[k].get("SQ_WAIT_ANY", 0)),
+                           "wait_inst_any": int(sq[k].get("SQ_WAIT_INST_ANY", 0)), "active_inst_any": int(sq[k].get("SQ_ACTIVE_INST_ANY", 0)),
+                           "lds_insts": int(sq2.get(k, {}).get("SQ_INSTS_LDS", 0)), "waves": int(sq2.get(k, {}).get("SQ_WAVES", 0)),
+                           "kernel_cycles": int(sq2.get(k, {}).get("GRBM_GUI_ACTIVE", 0) / 8)}
+out_v["_note"] = ("rocprofv3 --pmc SQ_* passes of `bench.py --steps 3` (averages per launch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are "
+                  "quad-cycles summed over waves; kernel_cycles = GRBM_GUI_ACTIVE / 8)")
+json.dump(out_t, open(os.path.join(d, "pmc_traffic.json"), "w"), indent=1)
+json.dump(out_v, open(os.path.join(d, "pmc_valu.json"), "w"), indent=1)
+print(json.dumps(out_t, indent=1))
+print(json.dumps(out_v, indent=1))

@@ -144,3 +144,49 @@ def test_fused_adam_prune_and_cat_keep_moments_aligned():
     b = GradBucket(P2, dev); b.pack({n: t.to(dev) for n, t in g2.items()}); opt.step(b.flat)
     for n in ks:
         assert (soa.views[n].cpu().double() - ps2[n].detach()).abs().max() < 2e-6, n
+
+
+@pytest.mark.gpu
+def test_render_through_leaves_after_prune_and_cat():
+    """prune() / cat() re-allocate the flat SoA: leaves fetched before are stale (they alias the OLD buffer, so rendering
+    from them would silently ignore every later Adam step).  Fresh leaves render the new map; stale ones are rejected."""
+    from gaus_slam_amd import optim, render as gs_render
+    from gaus_slam_amd.scene_synth import make_scene, make_upstream_grads
+    dev = torch.device("cuda")
+    P, W, H = 3000, 160, 120
+    sc = make_scene(P, W, H, seed=5, regime="mapping")
+    names = ("means3D", "opacities", "scales", "rotations", "colors")
+    soa = optim.GaussianSoA({k: sc[k].to(dev) for k in names})
+    opt = optim.FusedGaussianAdam(soa, dict(xyz=1e-3, opacity=1e-2, scaling=1e-3, rotation=1e-3, rgb=1e-2))
+    settings = gs_render.settings_from_camera(sc["cam"], dev, use_sa=True)
+    dc, da = [t.to(dev) for t in make_upstream_grads(W, H, seed=2)]
+
+    def render_and_grads(leaves):
+        m2 = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        pkg = gs_render.render(settings, leaves["means3D"], m2, leaves["opacities"], colors_precomp=leaves["colors"],
+                               scales=leaves["scales"], rotations=leaves["rotations"])
+        torch.autograd.backward([pkg["render_color"], pkg["allmap"]], [dc, da])
+        return pkg["render_color"].detach().clone(), torch.cat([leaves[n].grad.reshape(-1) for n in optim.BUCKET_FIELDS])
+
+    old = soa.leaves()
+    img0, g0 = render_and_grads(old)
+    opt.step(g0, old)
+    keep = torch.ones(P, dtype=torch.bool, device=dev)
+    keep[::3] = False
+    opt.prune(keep)                                             # P changes ...
+    opt.cat({k: sc[k][: int((~keep).sum())].to(dev) for k in names})  # ... and is restored: same P, new buffer
+    assert soa.P == P
+    with pytest.raises(RuntimeError, match="stale Gaussian leaf"):
+        soa.assert_current(old)
+    with pytest.raises(RuntimeError, match="stale Gaussian leaf"):
+        opt.step(g0, old)
+    new = soa.leaves()
+    soa.assert_current(new)
+    img1, g1 = render_and_grads(new)
+    assert float((img1 - img0).abs().max()) > 1e-3  # the map did change
+    before = soa.flat.clone()
+    opt.step(g1, new)
+    assert not torch.equal(before, soa.flat)
+    # the fresh leaves alias the buffer Adam just updated: a second render sees the update without re-fetching
+    img2, _ = render_and_grads({k: v.detach().requires_grad_(True) for k, v in new.items()})
+    assert float((img2 - img1).abs().max()) > 0
