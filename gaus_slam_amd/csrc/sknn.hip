@@ -4,10 +4,12 @@
 // :77 and :218), whose source is NOT vendored in the mounted tree (.gitmodules:1-3).  Semantics restated from
 // its published behaviour: exact 3-NN over all other points (self excluded by index), best[] initialised to
 // FLT_MAX, result (b0+b1+b2)/3.  Algorithm here: 30-bit Morton codes -> radix sort (the rasterizer's own
-// wave64 sort) -> 64-point boxes with bounds -> one WAVE per box of queries (four independent waves per workgroup, no
-// barrier): the 64 Morton-neighbours of a wave need the same candidate boxes, so the wave selects them once (box-to-box
-// distance against its largest 3-NN radius, 64 boxes tested per step, one per lane), stages each candidate's 64 points
-// in wave-private LDS with one coalesced load and lets every lane scan them as LDS broadcasts behind its own pruning
+// wave64 sort) -> 64-point boxes with bounds (plus bounds of their runs of 8 and of groups of 64 boxes) -> one WAVE per box
+// of queries (four independent waves per workgroup, no barrier): the wave scans its own box and its two neighbours on the
+// curve, then walks the groups of 64 boxes outwards along the curve; a group whose AABB is beyond every run's 3-NN radius
+// is skipped whole, otherwise 64 boxes are tested at once (one per lane, against the 8 runs of queries), each wanted
+// candidate's 64 points are staged in wave-private LDS with one coalesced load and every lane scans them as LDS broadcasts
+// behind its own pruning
 // test.  The result is the exact k-NN set, so it equals a brute-force evaluation bit for bit (squared distances use
 // the same expression order; the three smallest distances do not depend on the evaluation order).
 #include "gs2d_common.h"
@@ -143,6 +145,18 @@ box_bounds_kernel(int N, const float4* __restrict__ sorted, float* __restrict__ 
     }
 }
 
+// super[g] = AABB of the 64 boxes of group g (one wave per group)
+__global__ void __launch_bounds__(64) super_bounds_kernel(const float* __restrict__ boxes, float* __restrict__ super, int nboxes)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float lo = wave_min(b < nboxes ? boxes[6 * b + a] : FLT_MAX);
+        const float hi = wave_max(b < nboxes ? boxes[6 * b + 3 + a] : -FLT_MAX);
+        if (threadIdx.x == 0) { super[6 * blockIdx.x + a] = lo; super[6 * blockIdx.x + 3 + a] = hi; }
+    }
+}
+
 __device__ __forceinline__ void update3(const float4 ref, const float4 p, float& b0, float& b1, float& b2)
 {
     const float dx = p.x - ref.x, dy = p.y - ref.y, dz = p.z - ref.z;
@@ -170,7 +184,7 @@ __device__ __forceinline__ float box_dist2(const float4 p, const float* bx)
 // One wave = the 64 consecutive (Morton-sorted) points of one box as queries; waves are independent.
 __global__ void __launch_bounds__(256)
 knn_kernel(int N, const float4* __restrict__ sorted, const uint32_t* __restrict__ order, const float* __restrict__ boxes,
-           const float* __restrict__ sub, int nboxes, float* __restrict__ out)
+           const float* __restrict__ sub, const float* __restrict__ super, int nboxes, float* __restrict__ out)
 {
     __shared__ float4 stage[4][BOX];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -191,27 +205,56 @@ knn_kernel(int N, const float4* __restrict__ sorted, const uint32_t* __restrict_
     WAVE_LDS_SYNC();
     for (int j = 0; j < BOX; j++)
         if (j != lane) update3(ref, pts[j], b0, b1, b2);
-    // Candidate boxes are selected per RUN of 8 queries, not for the whole wave: a box that straddles a jump of the Morton
-    // curve has a huge AABB whose gap to almost every other box is 0 (one such wave walked 1700 candidates and the kernel
-    // waited for it), its runs of 8 are compact.  qsub[r] = (AABB of run r, largest 3-NN radius among its queries).
+    // The two Morton neighbours of the query box first, unpruned: a box that straddles a jump of the curve leaves the few
+    // queries on one side of the jump without three neighbours in their own box (3-NN radius = the length of the jump),
+    // their true neighbours precede / follow them on the curve.  Without this, one such wave walked 1700 candidates.
+    for (int nb = qb - 1; nb <= qb + 1; nb += 2) {
+        if (nb < 0 || nb >= nboxes) continue;
+        const int j = nb * BOX + lane;
+        WAVE_LDS_SYNC();
+        pts[lane] = j < N ? sorted[j] : far;
+        WAVE_LDS_SYNC();
+        if (valid)
+            for (int t = 0; t < BOX; t++) update3(ref, pts[t], b0, b1, b2);
+    }
+    // Candidate boxes are selected per RUN of 8 queries, not for the whole wave: a straddling box has a huge AABB whose gap
+    // to almost every other box is 0, its runs of 8 are compact.  qsub[r] = (AABB of run r, largest 3-NN radius among its
+    // queries); the radius is refreshed after every group of 64 candidate boxes that contributed points.
     __shared__ float qsub_all[4][BOX / SUB][8];
     float (*qsub)[8] = qsub_all[wave];
-    {
-        float rmax = valid ? b2 : 0.f;
+    if ((lane & (SUB - 1)) == 0) {
+        const float* sb = sub + ((size_t)qb * (BOX / SUB) + lane / SUB) * 6;
 #pragma unroll
-        for (int d = 1; d < SUB; d <<= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, d, 64));
-        if ((lane & (SUB - 1)) == 0) {
-            const float* sb = sub + ((size_t)qb * (BOX / SUB) + lane / SUB) * 6;
-#pragma unroll
-            for (int a = 0; a < 6; a++) qsub[lane / SUB][a] = sb[a];
-            qsub[lane / SUB][6] = rmax;
-        }
+        for (int a = 0; a < 6; a++) qsub[lane / SUB][a] = sb[a];
     }
-    WAVE_LDS_SYNC();
-    for (int base = 0; base < nboxes; base += 64) {
+    const int ngroups = (nboxes + 63) >> 6, g0 = qb >> 6;
+    bool refresh = true;
+    // groups of 64 boxes, outwards from the query's own group along the curve: the near ones shrink the radii first
+    for (int k = 0; k < 2 * ngroups; k++) {
+        const int g = __builtin_amdgcn_readfirstlane((k & 1) ? g0 + ((k + 1) >> 1) : g0 - (k >> 1));
+        if (g < 0 || g >= ngroups) continue;
+        if (refresh) {
+            float rmax = valid ? b2 : 0.f;
+#pragma unroll
+            for (int d = 1; d < SUB; d <<= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, d, 64));
+            WAVE_LDS_SYNC();
+            if ((lane & (SUB - 1)) == 0) qsub[lane / SUB][6] = rmax;
+            WAVE_LDS_SYNC();
+            refresh = false;
+        }
+        {   // the whole group at once: lane r tests run r against the group's AABB
+            const float* gx = super + 6 * g;
+            const int r = lane & (BOX / SUB - 1);
+            const float d0 = fmaxf(0.f, fmaxf(gx[0] - qsub[r][3], qsub[r][0] - gx[3]));
+            const float d1 = fmaxf(0.f, fmaxf(gx[1] - qsub[r][4], qsub[r][1] - gx[4]));
+            const float d2 = fmaxf(0.f, fmaxf(gx[2] - qsub[r][5], qsub[r][2] - gx[5]));
+            const float dist = (d0 * d0 + d1 * d1) + d2 * d2;
+            if (__ballot(!(dist * 0.999999f > qsub[r][6])) == 0) continue;
+        }
+        const int base = g << 6;
         const int c = base + lane;
         bool want = false;
-        if (c < nboxes && c != qb) {
+        if (c < nboxes && (c < qb - 1 || c > qb + 1)) {
             const float* bx = boxes + 6 * c;
             const float c0 = bx[0], c1 = bx[1], c2 = bx[2], C0 = bx[3], C1 = bx[4], C2 = bx[5];
 #pragma unroll
@@ -226,6 +269,7 @@ knn_kernel(int N, const float4* __restrict__ sorted, const uint32_t* __restrict_
             }
         }
         uint64_t todo = __ballot(want);
+        refresh = todo != 0;
         // the next candidate's points are fetched while the current one is scanned
         int cb = todo ? base + __builtin_ctzll(todo) : 0;
         float4 nextp = far;
@@ -268,6 +312,8 @@ extern "C" int sknn_dist2(int N, const float* points, float* out, gs2d_alloc_fn 
     const size_t off_sorted = o; o = gs2d_align_up(o + sizeof(float4) * (size_t)N, 256);
     const size_t off_boxes = o; o = gs2d_align_up(o + sizeof(float) * 6 * (size_t)nboxes, 256);
     const size_t off_sub = o; o = gs2d_align_up(o + sizeof(float) * 6 * (BOX / SUB) * (size_t)nboxes, 256);
+    const int ngroups = (nboxes + 63) / 64;
+    const size_t off_super = o; o = gs2d_align_up(o + sizeof(float) * 6 * (size_t)ngroups, 256);
     const size_t off_bounds = o; o = gs2d_align_up(o + 64, 256);
     char* ws = (char*)ws_alloc(ws_user, o);
     if (!ws) return -1;
@@ -279,6 +325,7 @@ extern "C" int sknn_dist2(int N, const float* points, float* out, gs2d_alloc_fn 
     float4* sorted = (float4*)(ws + off_sorted);
     float* boxes = (float*)(ws + off_boxes);
     float* sub = (float*)(ws + off_sub);
+    float* super = (float*)(ws + off_super);
     uint32_t* bounds = (uint32_t*)(ws + off_bounds);
 
     hipLaunchKernelGGL(bounds_init_kernel, dim3(1), dim3(256), 0, s, bounds);
@@ -291,6 +338,7 @@ extern "C" int sknn_dist2(int N, const float* points, float* out, gs2d_alloc_fn 
     gs2d::launch_sort_pairs(N, keys, order, keys_alt, vals_alt, 0, end_bit, hist, BL.hist_elems, s);
     hipLaunchKernelGGL(gather_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, points, order, sorted);
     hipLaunchKernelGGL(box_bounds_kernel, dim3((nboxes + 3) / 4), dim3(256), 0, s, N, sorted, boxes, sub, nboxes);
-    hipLaunchKernelGGL(knn_kernel, dim3((nboxes + 3) / 4), dim3(256), 0, s, N, sorted, order, boxes, sub, nboxes, out);
+    hipLaunchKernelGGL(super_bounds_kernel, dim3(ngroups), dim3(64), 0, s, boxes, super, nboxes);
+    hipLaunchKernelGGL(knn_kernel, dim3((nboxes + 3) / 4), dim3(256), 0, s, N, sorted, order, boxes, sub, super, nboxes, out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
