@@ -85,6 +85,7 @@ StageTimer g_timer;
 
 // deterministic backward (opt-in, process-wide): must not change between a forward and its backward
 std::atomic<int> g_deterministic{0};
+std::atomic<int> g_reference_binning{0};
 
 // pinned host word for the num_rendered read-back (one per host thread)
 struct PinnedWord {
@@ -137,6 +138,8 @@ int gs2d_stage_timing_read(float ms[9])
 
 void gs2d_set_deterministic(int on) { g_deterministic.store(on != 0); }
 int gs2d_get_deterministic(void) { return g_deterministic.load(); }
+void gs2d_set_reference_binning(int on) { g_reference_binning.store(on != 0); }
+int gs2d_get_reference_binning(void) { return g_reference_binning.load(); }
 
 const char* gs2d_build_info(void) { return "gs2d-hip gfx950 strict-fp (fp-contract=off) " __DATE__; }
 
@@ -191,17 +194,19 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     cam.W = width; cam.H = height;
     cam.gx = (width + GS2D_TILE - 1) / GS2D_TILE;
     cam.gy = (height + GS2D_TILE - 1) / GS2D_TILE;
+    cam.tight = g_reference_binning.load() == 0;
 
     float* depths = (float*)(geom + GL.depths);
     uint32_t* tiles_touched = (uint32_t*)(geom + GL.tiles_touched);
     uint32_t* point_offsets = (uint32_t*)(geom + GL.point_offsets);
     float4* rec = (float4*)(geom + GL.rec);
     uint8_t* clamped = (uint8_t*)(geom + GL.clamped);
+    ushort4* rect = (ushort4*)(geom + GL.rect);
     uint32_t* scan_tmp = (uint32_t*)(geom + GL.scan_tmp);
 
     g_timer.begin(ST_PREPROCESS, s);
     gs2d::launch_preprocess_fwd(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, transMat_precomp,
-                                colors_precomp, cam, radii, depths, rec, tiles_touched, clamped, pose_Rt, pose_quat, scan_tmp,
+                                colors_precomp, cam, radii, depths, rec, tiles_touched, rect, clamped, pose_Rt, pose_quat, scan_tmp,
                                 s);
     g_timer.end(ST_PREPROCESS, s);
     GS2D_STAGE("preprocess");
@@ -281,8 +286,7 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     uint32_t* v_unsorted = (passes & 1) ? vals_alt : point_list;
     // always launched: it also completes point_offsets (all zeros when nothing is visible)
     g_timer.begin(ST_DUPLICATE, s);
-    gs2d::launch_duplicate(P, rec, depths, tiles_touched, scan_tmp, point_offsets, radii, cam.gx, cam.gy, k_unsorted,
-                           v_unsorted, s);
+    gs2d::launch_duplicate(P, rect, depths, tiles_touched, scan_tmp, point_offsets, cam.gx, k_unsorted, v_unsorted, s);
     g_timer.end(ST_DUPLICATE, s);
     GS2D_STAGE("duplicate");
     if (R > 0) {
@@ -390,7 +394,8 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
             gs2d::launch_blend_bwd(width, height, ranges, point_list, rec, background, pix_state, hits, dL_dpix, dL_depths,
                                    grad_rec, use_sa, det_slots, s);
         }
-        gs2d::launch_det_reduce(P, R, width, height, ranges, point_list, rec, radii, (const uint32_t*)(geom_buffer + GL.tiles_touched),
+        gs2d::launch_det_reduce(P, R, width, height, ranges, point_list, (const ushort4*)(geom_buffer + GL.rect),
+                                (const uint32_t*)(geom_buffer + GL.tiles_touched),
                                 (const uint32_t*)(geom_buffer + GL.point_offsets), hits, det_inv, det_slots, grad_rec, s);
         g_timer.end(ST_BLEND_BWD, s);
         GS2D_STAGE("blend_bwd (deterministic)");
@@ -405,6 +410,7 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         cam.H = (int)(focal_y * tan_fovy * 2);
         cam.gx = (width + GS2D_TILE - 1) / GS2D_TILE;
         cam.gy = (height + GS2D_TILE - 1) / GS2D_TILE;
+        cam.tight = 0;
         g_timer.begin(ST_PREPROCESS_BWD, s);
         gs2d::launch_preprocess_bwd(g_begin, g_end, D, M, means3D, rec, radii, shs, clamped, scales, rotations, cam, grad_rec,
                                     dL_dtransMat, dL_dnormal, dL_dcolor, dL_dopacity, dL_dsh, dL_dmean2D, dL_dmean3D,

@@ -107,12 +107,12 @@ __device__ __forceinline__ int f2i_sat(float v)
     return (int)v;
 }
 
-// rasterizer_impl.cu:70-111; one thread per Gaussian, tiles emitted row-major (y outer, x inner).
+// rasterizer_impl.cu:70-111; one thread per Gaussian, tiles emitted row-major (y outer, x inner).  The rectangle comes
+// from the preprocess kernel (the reference's, or its intersection with the footprint bound), not re-derived from radii.
 __global__ void __launch_bounds__(256)
-duplicate_kernel(int P, const float4* __restrict__ rec, const float* __restrict__ depths,
+duplicate_kernel(int P, const ushort4* __restrict__ rect, const float* __restrict__ depths,
                  const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_offsets,
-                 uint32_t* __restrict__ point_offsets, const int* __restrict__ radii, int gx, int gy,
-                 uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+                 uint32_t* __restrict__ point_offsets, int gx, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     // The prefix sum of tiles_touched (rasterizer_impl.cu:283) is finished here: the preprocess kernel left one sum per
     // 256 Gaussians, scan_blocksums_kernel turned those into exclusive block offsets, and this workgroup (the same 256
@@ -122,19 +122,13 @@ duplicate_kernel(int P, const float4* __restrict__ rec, const float* __restrict_
     const uint32_t incl = block_offsets[blockIdx.x] + block_incl_scan(mine, nullptr);
     if (idx >= P) return;
     point_offsets[idx] = incl;  // inclusive offsets, as the reference's InclusiveSum leaves them
-    const int rad = radii[idx];
-    if (rad <= 0) return;
+    if (mine == 0u) return;
     uint32_t off = incl - mine;
-    const float px = rec[(size_t)idx * GS2D_REC_F4 + 0].w, py = rec[(size_t)idx * GS2D_REC_F4 + 1].w;
-    const float r = (float)rad;
-    const int minx = min(gx, max(0, f2i_sat((px - r) / (float)GS2D_TILE)));
-    const int miny = min(gy, max(0, f2i_sat((py - r) / (float)GS2D_TILE)));
-    const int maxx = min(gx, max(0, f2i_sat((px + r + (float)(GS2D_TILE - 1)) / (float)GS2D_TILE)));
-    const int maxy = min(gy, max(0, f2i_sat((py + r + (float)(GS2D_TILE - 1)) / (float)GS2D_TILE)));
+    const ushort4 r = rect[idx];
     const uint32_t dbits = __float_as_uint(depths[idx]);
-    for (int y = miny; y < maxy; y++)
-        for (int x = minx; x < maxx; x++) {
-            const uint64_t key = ((uint64_t)((uint32_t)y * (uint32_t)gx + (uint32_t)x) << 32) | dbits;
+    for (uint32_t y = r.y; y < r.w; y++)
+        for (uint32_t x = r.x; x < r.z; x++) {
+            const uint64_t key = ((uint64_t)(y * (uint32_t)gx + x) << 32) | dbits;
             keys[off] = key;
             vals[off] = (uint32_t)idx;
             off++;
@@ -462,12 +456,12 @@ void launch_offsets_blocksums(int P, uint32_t* block_sums, uint32_t* total_dev, 
     hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_T), 0, s, block_sums, (P + 255) / 256, total_dev, total_host);
 }
 
-void launch_duplicate(int P, const float4* rec, const float* depths, const uint32_t* tiles_touched,
-                      const uint32_t* block_offsets, uint32_t* point_offsets, const int* radii, int gx, int gy,
-                      uint64_t* keys, uint32_t* vals, hipStream_t s)
+void launch_duplicate(int P, const ushort4* rect, const float* depths, const uint32_t* tiles_touched,
+                      const uint32_t* block_offsets, uint32_t* point_offsets, int gx, uint64_t* keys, uint32_t* vals,
+                      hipStream_t s)
 {
-    hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, rec, depths, tiles_touched, block_offsets,
-                       point_offsets, radii, gx, gy, keys, vals);
+    hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, rect, depths, tiles_touched, block_offsets,
+                       point_offsets, gx, keys, vals);
 }
 
 void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int begin_bit,

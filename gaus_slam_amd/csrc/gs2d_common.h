@@ -30,7 +30,7 @@ enum { PS_TFINAL = 0, PS_M1, PS_M2, PS_MEDIAN, PS_STD, PS_LAST, PS_MEDC, PS_PLAN
 static inline size_t gs2d_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t depths, tiles_touched, point_offsets, rec, clamped, scan_tmp, grad_rec, total;
+    size_t depths, tiles_touched, point_offsets, rec, clamped, scan_tmp, grad_rec, rect, total;
 };
 struct BinLayout {
     size_t point_list, hits, keys, vals_alt, keys_alt, hist, det_inv, det_slots, total;
@@ -62,6 +62,8 @@ static inline GeomLayout geom_layout(int P)
     L.scan_tmp = o; o = gs2d_align_up(o + 4 * (nblk + 64), 256);
     // backward-time accumulator (the reference backward has no allocator callback, so it is reserved here)
     L.grad_rec = o; o = gs2d_align_up(o + 4 * GS2D_GRAD_FLOATS * p, 256);
+    // tile rectangle [minx, maxx) x [miny, maxy) of every Gaussian as four u16 (preprocess -> duplicate / det_inverse)
+    L.rect = o; o = gs2d_align_up(o + 8 * p, 256);
     L.total = o;
     return L;
 }
@@ -114,14 +116,50 @@ struct CamParams {
     const float* campos;  // device, 3 floats
     int W, H;      // forward: true size; backward: size rebuilt as the reference does (backward.cu:641-642)
     int gx, gy;
+    int tight;     // forward: shrink every Gaussian's tile rectangle to its footprint bound (gs2d_footprint)
 };
+
+// Conservative bound of the pixels a splat can reach with alpha >= 1/255, i.e. min(rho3d, rho2d) <= rho_max
+// (rho_max = 2 ln(255 opacity) + margin, record slot q4.z).  Shared by the preprocess kernel (tile rectangle of the
+// Gaussian) and the cull kernel (sub-blocks of one tile) so that both use bit-identical numbers:
+//  * {rho2d <= rho_max} is a disc of radius sqrt(rho_max/100) px around the stored centre (q0.w, q1.w): rl, +0.5 px margin;
+//  * {rho3d <= rho_max} is the image of the surfel's disc u^2+v^2 <= rho_max.  When that disc lies safely in front of
+//    the eye the image is an ellipse and its exact AABB [cx-ex, cx+ex] x [cy-ey, cy+ey] follows from the closed form
+//    the reference uses for its 3-sigma box (forward.cu:119-147) with cutoff^2 = rho_max; mx, my are rounding margins.
+// kind: 0 = the splat can never reach 1/255, 1 = bounded (disc + ellipse), 2 = no safe bound (only the disc part is valid).
+// Cull-only math: hardware sqrt / rcp, the margins cover their ulps.
+struct Gs2dFootprint {
+    float rl, cx, cy, ex, ey, mx, my;
+    int kind;
+};
+__device__ __forceinline__ Gs2dFootprint gs2d_footprint(const float4 q0, const float4 q1, const float4 q2, float rho_max)
+{
+    Gs2dFootprint f;
+    f.rl = 0.f; f.cx = 0.f; f.cy = 0.f; f.ex = 0.f; f.ey = 0.f; f.mx = 0.f; f.my = 0.f; f.kind = 0;
+    if (!(rho_max >= 0.f)) return f;  // opacity*G can never reach 1/255 (NaN opacity is encoded as +huge)
+    f.rl = __builtin_amdgcn_sqrtf(rho_max * (1.0f / GS2D_FILTER_INV_SQ)) + 0.5f;
+    f.kind = 2;
+    const float a = rho_max * (q2.x * q2.x + q2.y * q2.y), zz = q2.z * q2.z;
+    if (!(a <= 0.9f * zz) || !(q2.z > 0.f)) return f;  // disc not safely in front of the eye: no bound
+    const float inv = __builtin_amdgcn_rcpf(a - zz);
+    const float f0 = rho_max * inv, f2 = -inv;
+    f.cx = f0 * (q0.x * q2.x + q0.y * q2.y) + f2 * (q0.z * q2.z);
+    f.cy = f0 * (q1.x * q2.x + q1.y * q2.y) + f2 * (q1.z * q2.z);
+    const float hx = f.cx * f.cx - (f0 * (q0.x * q0.x + q0.y * q0.y) + f2 * (q0.z * q0.z));
+    const float hy = f.cy * f.cy - (f0 * (q1.x * q1.x + q1.y * q1.y) + f2 * (q1.z * q1.z));
+    if (!(hx == hx) || !(hy == hy)) return f;
+    f.ex = __builtin_amdgcn_sqrtf(fmaxf(hx, 0.f)); f.ey = __builtin_amdgcn_sqrtf(fmaxf(hy, 0.f));
+    f.mx = 0.5f + 0.02f * f.ex + 1e-4f * fabsf(f.cx); f.my = 0.5f + 0.02f * f.ey + 1e-4f * fabsf(f.cy);
+    f.kind = 1;
+    return f;
+}
 
 // Internal launchers (defined in the .hip files).
 namespace gs2d {
 void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
                            const float* rotations, const float* opacities, const float* shs,
                            const float* transMat_precomp, const float* colors_precomp, const CamParams& cam,
-                           int* radii, float* depths, float4* rec, uint32_t* tiles_touched, uint8_t* clamped,
+                           int* radii, float* depths, float4* rec, uint32_t* tiles_touched, ushort4* rect, uint8_t* clamped,
                            const float* pose_Rt, const float* pose_q, uint32_t* block_sums, hipStream_t s);
 // Gaussians [first, P)
 void launch_preprocess_bwd(int first, int P, int D, int M, const float* means3D, const float4* rec, const int* radii,
@@ -140,9 +178,9 @@ void launch_inclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* t
 // block_sums; launch_offsets_blocksums scans them in place (exclusive) and publishes the total (device word + optional
 // pinned host word, system-scope store); launch_duplicate adds each block's own scan and writes point_offsets.
 void launch_offsets_blocksums(int P, uint32_t* block_sums, uint32_t* total_dev, uint32_t* total_host, hipStream_t s);
-void launch_duplicate(int P, const float4* rec, const float* depths, const uint32_t* tiles_touched,
-                      const uint32_t* block_offsets, uint32_t* point_offsets, const int* radii, int gx, int gy,
-                      uint64_t* keys, uint32_t* vals, hipStream_t s);
+void launch_duplicate(int P, const ushort4* rect, const float* depths, const uint32_t* tiles_touched,
+                      const uint32_t* block_offsets, uint32_t* point_offsets, int gx, uint64_t* keys, uint32_t* vals,
+                      hipStream_t s);
 // stable LSD radix sort of (u64 key, u32 val) pairs on key bits [begin_bit, end_bit). Result lands in keys_a/vals_a;
 // the unsorted input must sit in the "b" buffers when the pass count ceil((end-begin)/8) is odd, else in "a".
 void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int begin_bit,
@@ -169,7 +207,7 @@ void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_l
                       const float* bg, const float* pix_state, const uint8_t* hits, const float* dL_dpix,
                       const float* dL_dothers, float* grad_rec, int use_sa, float* det_slots, hipStream_t s);
 // deterministic mode: inv[unsorted instance] = sorted position, then grad_rec[g] = sum of g's slots in a fixed order
-void launch_det_reduce(int P, int R, int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
-                       const int* radii, const uint32_t* tiles_touched, const uint32_t* point_offsets, const uint8_t* hits,
+void launch_det_reduce(int P, int R, int W, int H, const uint2* ranges, const uint32_t* point_list, const ushort4* rect,
+                       const uint32_t* tiles_touched, const uint32_t* point_offsets, const uint8_t* hits,
                        uint32_t* inv, const float* det_slots, float* grad_rec, hipStream_t s);
 }  // namespace gs2d

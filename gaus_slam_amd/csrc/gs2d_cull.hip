@@ -44,10 +44,7 @@ __device__ __forceinline__ int sub_bit(int sx, int sy) { return 8 * (sy >> 1) + 
 // Conservative test "can this splat reach alpha >= 1/255 on any pixel of sub-block (sx, sy)?" for all sixteen sub-blocks
 // of the tile whose first pixel is (tx0, ty0).  rho_max = 2 ln(255 opacity) (+margin, from the preprocess kernel):
 //   alpha >= 1/255  <=>  min(rho3d, rho2d) <= rho_max.
-//  (1) {rho2d <= rho_max} is a disc of radius sqrt(rho_max/100) px around the stored centre.
-//  (2) {rho3d <= rho_max} is the image of the disc u^2+v^2 <= rho_max of the surfel.  When that disc lies safely in front
-//      of the eye the image is an ellipse; its exact AABB follows from the closed form the reference uses for its 3-sigma
-//      box (forward.cu:119-147) with cutoff^2 = rho_max.
+//  (1), (2) the disc {rho2d <= rho_max} and the AABB of the ellipse {rho3d <= rho_max}: gs2d_footprint (gs2d_common.h).
 //  (3) Inside the AABB the ellipse itself is tested: with k = x Tw - Tu, l = y Tw - Tv the kernel's p = k x l is LINEAR in
 //      the pixel, p = A dx + B dy + C (A = Tw x l, B = k x Tw, C = k x l at the tile centre), so
 //      F = p.x^2 + p.y^2 - rho_max p.z^2 is an exact quadratic whose sign is the sign of rho3d - rho_max.  For a convex F
@@ -58,21 +55,13 @@ __device__ __forceinline__ int sub_bit(int sx, int sy) { return 8 * (sy >> 1) + 
 __device__ __forceinline__ uint32_t splat_touch_mask16(const float4 q0, const float4 q1, const float4 q2, float rho_max,
                                                        float tx0, float ty0)
 {
-    if (!(rho_max >= 0.f)) return 0u;  // opacity*G can never reach 1/255 (NaN opacity is encoded as +huge)
-    const float rl = fast_sqrt(rho_max * (1.0f / GS2D_FILTER_INV_SQ)) + 0.5f;  // cull-only math: hardware sqrt/rcp, margins cover the ulps
+    const Gs2dFootprint fp = gs2d_footprint(q0, q1, q2, rho_max);  // disc + ellipse AABB, shared with the preprocess kernel
+    if (fp.kind == 0) return 0u;
+    const float rl = fp.rl;
     // low-pass disc {rho2d <= rho_max}: bounding box of the disc against the sub-block columns / rows
     const uint32_t lp = col_mask(interval_cols(q0.w - rl, q0.w + rl, tx0)) & row_mask(interval_cols(q1.w - rl, q1.w + rl, ty0));
-    const float a = rho_max * (q2.x * q2.x + q2.y * q2.y), zz = q2.z * q2.z;
-    if (!(a <= 0.9f * zz) || !(q2.z > 0.f)) return 0xFFFFu;  // disc not safely in front of the eye: no bound
-    const float inv = fast_rcp(a - zz);
-    const float f0 = rho_max * inv, f2 = -inv;
-    const float cx = f0 * (q0.x * q2.x + q0.y * q2.y) + f2 * (q0.z * q2.z);
-    const float cy = f0 * (q1.x * q2.x + q1.y * q2.y) + f2 * (q1.z * q2.z);
-    const float hx = cx * cx - (f0 * (q0.x * q0.x + q0.y * q0.y) + f2 * (q0.z * q0.z));
-    const float hy = cy * cy - (f0 * (q1.x * q1.x + q1.y * q1.y) + f2 * (q1.z * q1.z));
-    if (!(hx == hx) || !(hy == hy)) return 0xFFFFu;
-    const float ex = fast_sqrt(fmaxf(hx, 0.f)), ey = fast_sqrt(fmaxf(hy, 0.f));
-    const float mx = 0.5f + 0.02f * ex + 1e-4f * fabsf(cx), my = 0.5f + 0.02f * ey + 1e-4f * fabsf(cy);
+    if (fp.kind == 2) return 0xFFFFu;
+    const float cx = fp.cx, cy = fp.cy, ex = fp.ex, ey = fp.ey, mx = fp.mx, my = fp.my;
     // AABB of the ellipse / its centre against the sub-block columns and rows
     const uint32_t in_aabb = col_mask(interval_cols(cx - ex - mx, cx + ex + mx, tx0)) & row_mask(interval_cols(cy - ey - my, cy + ey + my, ty0));
     if (in_aabb == 0u) return lp;  // the ellipse's AABB misses the tile

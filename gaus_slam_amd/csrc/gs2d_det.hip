@@ -8,18 +8,10 @@
 
 namespace {
 
-__device__ __forceinline__ int f2i_sat(float v)
-{
-    if (!(v == v)) return 0;
-    if (v >= 2147483648.0f) return 2147483647;
-    if (v <= -2147483648.0f) return (int)(-2147483647 - 1);
-    return (int)v;
-}
-
 // inv[first unsorted instance of g + (tile's index in g's rectangle)] = sorted position; one workgroup per tile
 __global__ void __launch_bounds__(256)
-det_inverse_kernel(int gx, int gy, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                   const float4* __restrict__ rec, const int* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
+det_inverse_kernel(int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                   const ushort4* __restrict__ rect, const uint32_t* __restrict__ tiles_touched,
                    const uint32_t* __restrict__ point_offsets, uint32_t* __restrict__ inv)
 {
     const int tile = blockIdx.x;
@@ -28,13 +20,8 @@ det_inverse_kernel(int gx, int gy, int ntiles, const uint2* __restrict__ ranges,
     const int tx = tile % gx, ty = tile / gx;
     for (uint32_t i = range.x + threadIdx.x; i < range.y; i += 256) {
         const uint32_t id = point_list[i];
-        // the rectangle exactly as duplicate_kernel (gs2d_binning.hip) computes it
-        const float px = rec[(size_t)id * GS2D_REC_F4 + 0].w, py = rec[(size_t)id * GS2D_REC_F4 + 1].w;
-        const float r = (float)radii[id];
-        const int minx = min(gx, max(0, f2i_sat((px - r) / (float)GS2D_TILE)));
-        const int miny = min(gy, max(0, f2i_sat((py - r) / (float)GS2D_TILE)));
-        const int maxx = min(gx, max(0, f2i_sat((px + r + (float)(GS2D_TILE - 1)) / (float)GS2D_TILE)));
-        const uint32_t local = (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
+        const ushort4 r = rect[id];  // the rectangle duplicate_kernel (gs2d_binning.hip) walked
+        const uint32_t local = (uint32_t)((ty - (int)r.y) * ((int)r.z - (int)r.x) + (tx - (int)r.x));
         inv[point_offsets[id] - tiles_touched[id] + local] = i;
     }
 }
@@ -70,13 +57,13 @@ det_reduce_kernel(int P, const uint32_t* __restrict__ tiles_touched, const uint3
 
 namespace gs2d {
 
-void launch_det_reduce(int P, int R, int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
-                       const int* radii, const uint32_t* tiles_touched, const uint32_t* point_offsets, const uint8_t* hits,
+void launch_det_reduce(int P, int R, int W, int H, const uint2* ranges, const uint32_t* point_list, const ushort4* rect,
+                       const uint32_t* tiles_touched, const uint32_t* point_offsets, const uint8_t* hits,
                        uint32_t* inv, const float* det_slots, float* grad_rec, hipStream_t s)
 {
     const int gx = (W + GS2D_TILE - 1) / GS2D_TILE, gy = (H + GS2D_TILE - 1) / GS2D_TILE;
     if (R > 0)
-        hipLaunchKernelGGL(det_inverse_kernel, dim3(gx * gy), dim3(256), 0, s, gx, gy, gx * gy, ranges, point_list, rec, radii,
+        hipLaunchKernelGGL(det_inverse_kernel, dim3(gx * gy), dim3(256), 0, s, gx, gx * gy, ranges, point_list, rect,
                            tiles_touched, point_offsets, inv);
     hipLaunchKernelGGL(det_reduce_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, tiles_touched, point_offsets, inv,
                        reinterpret_cast<const uint32_t*>(hits), det_slots, grad_rec);

@@ -177,8 +177,8 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       const float* __restrict__ shs, const float* __restrict__ transMat_precomp,
                       const float* __restrict__ colors_precomp, const CamParams cam, int* __restrict__ radii,
                       float* __restrict__ depths, float4* __restrict__ rec, uint32_t* __restrict__ tiles_touched,
-                      uint8_t* __restrict__ clamped, const float* __restrict__ pose_Rt, const float* __restrict__ pose_q,
-                      uint32_t* __restrict__ block_sums)
+                      ushort4* __restrict__ rect, uint8_t* __restrict__ clamped, const float* __restrict__ pose_Rt,
+                      const float* __restrict__ pose_q, uint32_t* __restrict__ block_sums)
 {
     __shared__ uint32_t wave_tiles[4];
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -186,6 +186,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     // forward.cu:183-184: invisible unless proven otherwise
     int out_radius = 0;
     uint32_t out_tiles = 0;
+    ushort4 out_rect = make_ushort4(0, 0, 0, 0);
     float out_depth = 0.f;
     float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0, r4 = r0;
 
@@ -239,7 +240,6 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         else { col[0] = colors_precomp[3 * idx]; col[1] = colors_precomp[3 * idx + 1]; col[2] = colors_precomp[3 * idx + 2]; }
         out_depth = pvz;
         out_radius = f2i_sat(radius);
-        out_tiles = (uint32_t)((maxy - miny) * (maxx - minx));
         r0 = make_float4(T[0], T[1], T[2], cx);
         r1 = make_float4(T[3], T[4], T[5], cy);
         r2 = make_float4(T[6], T[7], T[8], opacities[idx]);
@@ -249,10 +249,36 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         const float opa = opacities[idx];
         const float rho_max = opa > 0.f ? 2.0f * logf(255.0f * opa) * 1.0001f + 1e-3f : (opa == opa ? -1.f : 1e30f);
         r4 = make_float4(col[1], col[2], rho_max, 0.f);
+        // Tile rectangle.  Reference: the square of the 3-sigma radius (rasterizer_impl.cu:70-111 re-derives it from
+        // radii).  The pixels the splat can actually reach with alpha >= 1/255 lie inside its footprint bound, which is
+        // much smaller for the usual opacities (opacity 0.1 ends at 2.5 sigma, and the bound follows the ellipse instead
+        // of its circumscribed square): with cam.tight only the tiles of [reference rectangle] x [footprint bound] become
+        // instances -- every dropped (Gaussian, tile) pair is one whose pixels the reference would all `continue` past
+        // (forward.cu:385-387), so no output changes; the same bound, per sub-block, is what the cull kernel applies later.
+        if (cam.tight) {
+            const Gs2dFootprint fp = gs2d_footprint(r0, r1, r2, rho_max);
+            if (fp.kind == 0) { maxx = minx; maxy = miny; }
+            else if (fp.kind == 1) {
+                // 0.05 px of slack over the cull kernel's own intervals (it evaluates them per tile with other roundings)
+                const float lox = fminf(cx - fp.rl, fp.cx - fp.ex - fp.mx) - 0.05f, hix = fmaxf(cx + fp.rl, fp.cx + fp.ex + fp.mx) + 0.05f;
+                const float loy = fminf(cy - fp.rl, fp.cy - fp.ey - fp.my) - 0.05f, hiy = fmaxf(cy + fp.rl, fp.cy + fp.ey + fp.my) + 0.05f;
+                if (lox == lox && hix == hix && loy == loy && hiy == hiy) {
+                    // tile column t holds pixels 16 t .. 16 t + 15: met iff 16 t + 15 >= lo and 16 t <= hi
+                    minx = max(minx, f2i_sat(ceilf((lox - 15.f) * (1.0f / GS2D_TILE))));
+                    miny = max(miny, f2i_sat(ceilf((loy - 15.f) * (1.0f / GS2D_TILE))));
+                    maxx = min(maxx, min(f2i_sat(floorf(hix * (1.0f / GS2D_TILE))), cam.gx) + 1);
+                    maxy = min(maxy, min(f2i_sat(floorf(hiy * (1.0f / GS2D_TILE))), cam.gy) + 1);
+                    if (maxx <= minx || maxy <= miny) { maxx = minx; maxy = miny; }
+                }
+            }
+        }
+        out_tiles = (uint32_t)((maxy - miny) * (maxx - minx));
+        out_rect = make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy);
     } while (0);
     if (valid) {
         radii[idx] = out_radius;
         tiles_touched[idx] = out_tiles;
+        rect[idx] = out_rect;
         depths[idx] = out_depth;
         float4* rp = rec + (size_t)idx * GS2D_REC_F4;
         rp[0] = r0; rp[1] = r1; rp[2] = r2; rp[3] = r3; rp[4] = r4;
@@ -567,12 +593,12 @@ namespace gs2d {
 void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
                            const float* rotations, const float* opacities, const float* shs,
                            const float* transMat_precomp, const float* colors_precomp, const CamParams& cam,
-                           int* radii, float* depths, float4* rec, uint32_t* tiles_touched, uint8_t* clamped,
+                           int* radii, float* depths, float4* rec, uint32_t* tiles_touched, ushort4* rect, uint8_t* clamped,
                            const float* pose_Rt, const float* pose_q, uint32_t* block_sums, hipStream_t s)
 {
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, transMat_precomp, colors_precomp, cam, radii, depths,
-                       rec, tiles_touched, clamped, pose_Rt, pose_q, block_sums);
+                       rec, tiles_touched, rect, clamped, pose_Rt, pose_q, block_sums);
 }
 
 void launch_preprocess_bwd(int first, int P, int D, int M, const float* means3D, const float4* rec, const int* radii,

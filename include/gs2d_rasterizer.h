@@ -173,6 +173,21 @@ int gs2d_backward_staged(
 void gs2d_set_deterministic(int on);
 int gs2d_get_deterministic(void);
 
+/*
+ * Tile binning mode (process-wide; default 0).  The reference makes one (tile, Gaussian) instance for every tile of the
+ * square around a Gaussian's 3-sigma radius (rasterizer_impl.cu:70-111, auxiliary.h:66-76).  By default this library only
+ * makes the instances inside the splat's footprint bound -- the region where alpha can reach 1/255 at all, which depends on
+ * the opacity and follows the projected ellipse; every instance left out is one whose pixels the reference would all
+ * `continue` past (forward.cu:385-387), so colours, depth maps and gradients are unchanged (the forward outputs are
+ * bit-identical between the two modes, tests/test_gpu_footprint.py) while the sort and both blend passes handle about a
+ * quarter fewer instances.  Consequences of the default: num_rendered, tiles_touched and the per-tile lists are the
+ * reference's minus those instances (the lists are ordered subsequences of the reference's).  radii are the reference's.
+ * gs2d_set_reference_binning(1) switches to the reference's rectangles: then num_rendered and the sorted lists are
+ * bit-identical to the reference's (what the binning parity tests compare against the oracle).
+ */
+void gs2d_set_reference_binning(int on);
+int gs2d_get_reference_binning(void);
+
 /* present: [P] bytes (0/1). */
 int gs2d_mark_visible(int P, const float* means3D, const float* viewmatrix,
                       const float* projmatrix, uint8_t* present, void* stream);

@@ -140,6 +140,36 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, t
     return st
 
 
+def reblend(st, ranges, point_list, want_stability=True):
+    """The blend of forward() run again on OTHER per-tile lists (same preprocessed splats): returns a copy of the state
+    with ranges / point_list replaced and every blend output recomputed.  Used to show that lists with non-contributing
+    instances removed give the same image bit for bit (tests/test_gpu_footprint.py)."""
+    L = lib()
+    W, H = st["W"], st["H"]
+    HW = H * W
+    ranges = np.ascontiguousarray(ranges, dtype=np.uint32).reshape(-1, 2)
+    point_list = np.ascontiguousarray(point_list, dtype=np.uint32)
+    assert ranges.shape == st["ranges"].shape
+    out_color = np.zeros((3, H, W), np.float32)
+    out_others = np.zeros((7, H, W), np.float32)
+    final_T = np.zeros(3 * HW, np.float32)
+    n_contrib = np.zeros(2 * HW, np.uint32)
+    median_depth = np.zeros(HW, np.float32)
+    depth_std = np.zeros(HW, np.float32)
+    stab = np.full(HW, 1e30, np.float32) if want_stability else None
+    features = st["colors_precomp"] if st["colors_precomp"] is not None else st["rgb"]
+    tm = st["transMat_precomp"] if st["transMat_precomp"] is not None else st["transMats"]
+    if st["P"] > 0:
+        L.orc_blend_fwd(C.c_int(W), C.c_int(H), _p(ranges), _p(point_list), _p(st["means2D"]), _p(features),
+                        _p(tm), _p(st["normal_opacity"]), _p(st["bg"]), C.c_int(int(st["use_sa"])),
+                        _p(out_color), _p(out_others), _p(final_T), _p(n_contrib),
+                        _p(median_depth), _p(depth_std), _p(stab))
+    new = dict(st)
+    new.update(num_rendered=int(len(point_list)), ranges=ranges, point_list=point_list, color=out_color, allmap=out_others,
+               final_T=final_T, n_contrib=n_contrib, median_depth=median_depth, depth_std=depth_std, stability=stab)
+    return new
+
+
 def pixel_variants(st, px, py, knife, max_decisions=6):
     """All outcomes of the forward blend at pixel (px, py) when the decisions within `knife` (relative) of their threshold
     are flipped in every combination (orc_blend_fwd_pixel).  Returns (n_decisions, list of dicts color[3], others[7],

@@ -84,8 +84,14 @@ def test_posed_kernels_match_oracle(oracle, use_sa):
     args = (torch.zeros(3, device=dev), t(sc["means3D"]), t(sc["colors"]), t(sc["opacities"]), t(sc["scales"]),
             t(sc["rotations"]), 1.0, e, t(cam.viewmatrix), t(cam.projmatrix), cam.tanfovx, cam.tanfovy, H, W, e, 0,
             t(cam.campos), use_sa, False, False)
+    rasterizer.set_reference_binning(True)  # the oracle's instance count is the reference's
+    try:
+        R_ref = rasterizer.rasterize_gaussians(*args, pose_Rt=t(Rt), pose_quat=t(qc))[0]
+    finally:
+        rasterizer.set_reference_binning(False)
+    assert R_ref == o["num_rendered"]
     R, color, allmap, radii, geom, binning, img = rasterizer.rasterize_gaussians(*args, pose_Rt=t(Rt), pose_quat=t(qc))
-    assert R == o["num_rendered"]
+    assert 0 < R <= R_ref  # default binning: only the tiles inside the footprint bound
     np.testing.assert_array_equal(radii.cpu().numpy(), o["radii"])  # bit-exact geometry through the fused transform
     stable = (o["stability"] > 2e-5).reshape(H, W)
     assert np.abs(color.cpu().numpy() - o["color"])[:, stable].max() <= 1e-4

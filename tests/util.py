@@ -40,9 +40,20 @@ def pix_index_map(W, H):
 
 
 def hip_forward(sc, use_sa=True, bg=(0.0, 0.0, 0.0), shs=None, sh_degree=0, transMat_precomp=None, scale_modifier=1.0,
-                debug=False, device="cuda"):
+                debug=False, device="cuda", binning="reference"):
     """Calls the C-ABI forward through gaus_slam_amd.rasterizer.rasterize_gaussians and unpacks the private
-    scratch layout for comparison."""
+    scratch layout for comparison.  binning: "reference" = the reference's 3-sigma tile rectangles (gs2d_set_reference_binning,
+    what the bit-exact list comparisons need), "footprint" = the library's default (tests/test_gpu_footprint.py)."""
+    from gaus_slam_amd import rasterizer
+    assert binning in ("reference", "footprint")
+    rasterizer.set_reference_binning(binning == "reference")
+    try:
+        return _hip_forward(sc, use_sa, bg, shs, sh_degree, transMat_precomp, scale_modifier, debug, device)
+    finally:
+        rasterizer.set_reference_binning(False)  # the library default
+
+
+def _hip_forward(sc, use_sa, bg, shs, sh_degree, transMat_precomp, scale_modifier, debug, device):
     from gaus_slam_amd import _lib, rasterizer
     cam = sc["cam"]
     dev = torch.device(device)
