@@ -246,10 +246,16 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
     from gaus_slam_amd import rasterizer
     with torch.no_grad():
         e = torch.empty(0, device=dev)
-        R = rasterizer.rasterize_gaussians(settings.bg, params["means3D"], params["colors"], params["opacities"],
-                                           params["scales"], params["rotations"], 1.0, e, settings.viewmatrix,
-                                           settings.projmatrix, settings.tanfovx, settings.tanfovy, H, W, e, 0,
-                                           settings.campos, use_sa, False, False)[0]
+        count = lambda: rasterizer.rasterize_gaussians(settings.bg, params["means3D"], params["colors"], params["opacities"],
+                                                       params["scales"], params["rotations"], 1.0, e, settings.viewmatrix,
+                                                       settings.projmatrix, settings.tanfovx, settings.tanfovy, H, W, e, 0,
+                                                       settings.campos, use_sa, False, False)[0]
+        R = count()  # instances the timed path handles (footprint binning, the library default)
+        rasterizer.set_reference_binning(True)
+        try:
+            R_ref = count()  # instances of the reference's 3-sigma rectangles, for comparison only
+        finally:
+            rasterizer.set_reference_binning(False)
     sb = stage_bytes(P, R, H * W)
     dom = max(("blend_fwd", "blend_bwd", "sort", "cull", "preprocess", "preprocess_bwd"), key=lambda n: stage_ms[n])
     achieved = sb[dom] / (stage_ms[dom] * 1e-3) / 1e9
@@ -308,7 +314,7 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"synthetic {W}x{H} / {P} Gaussians ({args.workload}; BASELINE.md section 2), {regime} regime, "
-                               f"use_sa={use_sa}, {kpg} keyframe{'s' if kpg > 1 else ''} per GPU" + (f" on {args.streams} HIP streams" if kpg > 1 and args.streams > 1 else ""), "num_rendered": R, "visible": visible,
+                               f"use_sa={use_sa}, {kpg} keyframe{'s' if kpg > 1 else ''} per GPU" + (f" on {args.streams} HIP streams" if kpg > 1 and args.streams > 1 else ""), "num_rendered": R, "num_rendered_reference_rects": R_ref, "visible": visible,
                    "step": "op forward+backward" + (" + all-reduce of the [P,13] grad bucket" if world > 1 else "")
                            + (f" + {args.adam} Adam (lr=0)" if args.adam else ""),
                    "parallelism": f"keyframe-sharded x{world}", "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4)},

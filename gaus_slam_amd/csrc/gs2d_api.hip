@@ -9,6 +9,7 @@
 #include <chrono>
 #include <string>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #if defined(__x86_64__) || defined(__i386__)
 #include <immintrin.h>
@@ -95,6 +96,26 @@ struct PinnedWord {
 thread_local PinnedWord g_pinned;
 // previous forward's num_rendered for the same problem shape: sizes the early binning allocation (a guess only: the
 // chunk is re-requested with the exact size when the guess was too small)
+// Geometry chunks whose gradient accumulator (grad_rec) is known to be all zero: the forward's blend kernel clears it with
+// spare store slots, so the first backward on that chunk needs no memset (7 us on the critical path at 500k Gaussians).
+// A chunk enters when its forward launched the blend kernel and leaves when a forward starts on it or a backward takes it; a
+// backward that does not find its chunk here (second backward on the same forward, R == 0, more than 8 forwards in
+// flight) clears the accumulator itself.
+struct CleanChunks {
+    std::mutex m;
+    const void* p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int next = 0;
+    void drop(const void* q) { std::lock_guard<std::mutex> l(m); for (auto& e : p) if (e == q) e = nullptr; }
+    void add(const void* q) { std::lock_guard<std::mutex> l(m); p[next] = q; next = (next + 1) & 7; }
+    bool take(const void* q)
+    {
+        std::lock_guard<std::mutex> l(m);
+        for (auto& e : p) if (e == q) { e = nullptr; return true; }
+        return false;
+    }
+};
+CleanChunks g_clean;
+
 struct LastCount { int P = -1, W = 0, H = 0; uint32_t R = 0; };
 thread_local LastCount g_last;
 
@@ -187,6 +208,7 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     const GeomLayout GL = geom_layout(P);
     char* geom = (char*)geometry_alloc(geometry_user, GL.total);
     if (!geom) return fail_msg("geometry allocation failed");
+    g_clean.drop(geom);
     const ImgLayout IL = img_layout(width, height);
 
     CamParams cam;
@@ -317,7 +339,8 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     }
     g_timer.begin(ST_BLEND_FWD, s);
     gs2d::launch_blend_fwd(width, height, ranges, point_list, rec, background, out_color, out_others, pix_state, hits,
-                           use_sa, s);
+                           use_sa, (float4*)(geom + GL.grad_rec), (size_t)P * (GS2D_GRAD_FLOATS / 4), s);
+    g_clean.add(geom);
     g_timer.end(ST_BLEND_FWD, s);
     GS2D_STAGE("blend_fwd");
     return R;
@@ -375,7 +398,8 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
     const float* pix_state = (const float*)(img_buffer + IL.pix);
 
     if ((stages & 1) != 0 && !det) {
-        GS2D_CHECK(hipMemsetAsync(grad_rec, 0, sizeof(float) * GS2D_GRAD_FLOATS * (size_t)P, s), "memset grad_rec");
+        if (!g_clean.take(geom_buffer))  // else: cleared by the forward's blend kernel, nothing has touched it since
+            GS2D_CHECK(hipMemsetAsync(grad_rec, 0, sizeof(float) * GS2D_GRAD_FLOATS * (size_t)P, s), "memset grad_rec");
         if (R > 0) {
             g_timer.begin(ST_BLEND_BWD, s);
             gs2d::launch_blend_bwd(width, height, ranges, point_list, rec, background, pix_state, hits, dL_dpix, dL_depths,
@@ -388,6 +412,7 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         // no atomics: per-(instance, quadrant) partial records, then a fixed-order sum per Gaussian (gs2d_det.hip)
         float* det_slots = (float*)(binning_buffer + BL.det_slots);
         uint32_t* det_inv = (uint32_t*)(binning_buffer + BL.det_inv);
+        (void)g_clean.take(geom_buffer);  // det_reduce overwrites the accumulator: no longer "known zero"
         g_timer.begin(ST_BLEND_BWD, s);
         if (R > 0) {
             GS2D_CHECK(hipMemsetAsync(det_slots, 0, sizeof(float) * GS2D_GRAD_FLOATS * 4 * (size_t)R, s), "memset det_slots");

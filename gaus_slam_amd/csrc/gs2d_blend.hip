@@ -203,15 +203,25 @@ __device__ __forceinline__ int rank_below(uint64_t b)
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
 }
 
+// Side job of the forward blend: clear the backward's gradient accumulator with this kernel's idle store path (fire-and-
+// forget stores as every wave finishes), so that the backward starts without a memset on its critical path.  Every
+// thread of the grid takes its share, the padding workgroups too.
+__device__ __forceinline__ void clear_share(float4* __restrict__ zero, size_t zero_n)
+{
+    for (size_t z = (size_t)blockIdx.x * 256 + threadIdx.x; z < zero_n; z += (size_t)gridDim.x * 256)
+        zero[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 template <bool USE_SA>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS2D_FWD_WAVES_PER_EU, GS2D_FWD_WAVES_PER_EU)))
 blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
-                 float* __restrict__ out_others, float* __restrict__ pix_state, size_t plane, const uint8_t* __restrict__ hits)
+                 float* __restrict__ out_others, float* __restrict__ pix_state, size_t plane, const uint8_t* __restrict__ hits,
+                 float4* __restrict__ zero, size_t zero_n)
 {
     __shared__ FwdBatch batches[4];
     const int tile = xcd_tile(blockIdx.x, ntiles);
-    if (tile < 0) return;
+    if (tile < 0) { clear_share(zero, zero_n); return; }
     const int tx = tile % gx, ty = tile / gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     FwdBatch& wb = batches[wave];
@@ -370,6 +380,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
         reinterpret_cast<uint32_t*>(pix_state)[PS_LAST * plane + si] = last_contributor;
         reinterpret_cast<uint32_t*>(pix_state)[PS_MEDC * plane + si] = median_contributor;
     }
+    clear_share(zero, zero_n);
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -894,17 +905,17 @@ namespace gs2d {
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
                       const float* bg, float* out_color, float* out_others, float* pix_state, const uint8_t* hits, int use_sa,
-                      hipStream_t s)
+                      float4* zero, size_t zero_n, hipStream_t s)
 {
     const int gx = (W + GS2D_TILE - 1) / GS2D_TILE, gy = (H + GS2D_TILE - 1) / GS2D_TILE;
     const size_t plane = (size_t)gx * gy * GS2D_TILE_PIX;
     const int grid = GS2D_XCDS * ((gx * gy + GS2D_XCDS - 1) / GS2D_XCDS);
     if (use_sa)
         hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, W, H, gx, gx * gy, ranges, point_list, rec,
-                           bg, out_color, out_others, pix_state, plane, hits);
+                           bg, out_color, out_others, pix_state, plane, hits, zero, zero_n);
     else
         hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, W, H, gx, gx * gy, ranges, point_list, rec,
-                           bg, out_color, out_others, pix_state, plane, hits);
+                           bg, out_color, out_others, pix_state, plane, hits, zero, zero_n);
 }
 
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,

@@ -198,9 +198,10 @@ void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* key
 void launch_tile_ranges(int R, const uint64_t* keys, uint2* ranges, int tiles, hipStream_t s);
 // hits[4 * i + q]: low nibble = the 4x4 sub-blocks of quadrant q that instance i of the sorted list can touch
 void launch_cull(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec, uint8_t* hits, hipStream_t s);
+// also clears zero_n float4 at `zero` (the backward's gradient accumulator) with its idle store slots
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
                       const float* bg, float* out_color, float* out_others, float* pix_state, const uint8_t* hits, int use_sa,
-                      hipStream_t s);
+                      float4* zero, size_t zero_n, hipStream_t s);
 // det_slots != nullptr selects the deterministic variant: no atomics, per-(instance, quadrant) partial records
 // (GS2D_GRAD_FLOATS floats each, R * 4 of them, zero-initialised by the caller) that launch_det_reduce then sums
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,

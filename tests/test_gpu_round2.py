@@ -179,3 +179,20 @@ def test_deterministic_backward_is_bit_identical(oracle, P, W, H, channels):
         assert util.grad_err(g1[k], go[k].reshape(g1[k].shape)) <= GRAD_TOL, k
         assert util.grad_err(g_atomic[k], g1[k]) <= 1e-5, k
     assert np.abs(g1["dL_dmeans2D"]).max() > 0
+
+
+def test_second_backward_on_the_same_forward_is_clean():
+    """The first backward relies on the forward's cull kernel having cleared the gradient accumulator; a second backward on
+    the same forward state (retain_graph) must clear it itself: both give the same gradients."""
+    P, W, H = 20000, 320, 240
+    sc = util.make_scene(P, W, H, seed=4, regime="mapping")
+    dc, da = util.make_upstream_grads(W, H, channels=(0, 1, 2, 3, 4, 5, 6))
+    dc = (dc * W * H).numpy(); da = (da * W * H).numpy()
+    h = util.hip_forward(sc, binning="footprint")
+    g1 = util.hip_backward(h, dc, da)
+    g2 = util.hip_backward(h, dc, da)
+    g3 = util.hip_backward(h, 2 * dc, 2 * da)
+    for k in ["dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"]:
+        assert np.abs(g1[k]).max() > 0
+        assert util.grad_err(g2[k], g1[k]) <= 1e-5, k
+        assert util.grad_err(g3[k], 2 * g1[k]) <= 1e-5, k
