@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 # GS2D_LIB_PATH: load a pre-built variant instead (kernel experiments, scripts/dev/); never set in normal use
 LIB_PATH = os.environ.get("GS2D_LIB_PATH") or os.path.join(LIB_DIR, "libgs2d_hip.so")
-SOURCES = ["gs2d_preprocess.hip", "gs2d_binning.hip", "gs2d_cull.hip", "gs2d_blend.hip", "gs2d_det.hip", "gs2d_api.hip", "sknn.hip", "gs2d_loss.hip", "gs2d_adam.hip"]
+SOURCES = ["gs2d_preprocess.hip", "gs2d_binning.hip", "gs2d_blend.hip", "gs2d_det.hip", "gs2d_api.hip", "sknn.hip", "gs2d_loss.hip", "gs2d_adam.hip"]
 # -ffp-contract=off: the per-Gaussian geometry (tile rectangles, depth keys) must be reproducible on the host.
 # -fno-slp-vectorize: the SLP pass packs scalar fp32 ops into v_pk_* pairs; on gfx950 a packed op costs ~1.85 plain ones
 # (scripts/dev/issue_bench.hip) and assembling the register pairs took ~90 v_mov and 8 extra spills in blend_bwd.

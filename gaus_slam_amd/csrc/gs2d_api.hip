@@ -331,12 +331,6 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
         g_timer.end(ST_SORT, s);
         GS2D_STAGE("tile depth sort");
     }
-    if (R > 0) {
-        g_timer.begin(ST_CULL, s);
-        gs2d::launch_cull(width, height, ranges, point_list, rec, hits, s);
-        g_timer.end(ST_CULL, s);
-        GS2D_STAGE("cull");
-    }
     g_timer.begin(ST_BLEND_FWD, s);
     gs2d::launch_blend_fwd(width, height, ranges, point_list, rec, background, out_color, out_others, pix_state, hits,
                            use_sa, (float4*)(geom + GL.grad_rec), (size_t)P * (GS2D_GRAD_FLOATS / 4), s);

@@ -15,6 +15,7 @@
 // Arithmetic follows the oracle's expression order; the file is compiled with -ffp-contract=off so the
 // per-pixel recurrences reproduce the CPU oracle up to the ulp-level difference of v_exp_f32 / v_rcp_f32.
 #include "gs2d_common.h"
+#include "gs2d_cull.h"
 
 #include <type_traits>
 
@@ -216,7 +217,7 @@ template <bool USE_SA>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS2D_FWD_WAVES_PER_EU, GS2D_FWD_WAVES_PER_EU)))
 blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
-                 float* __restrict__ out_others, float* __restrict__ pix_state, size_t plane, const uint8_t* __restrict__ hits,
+                 float* __restrict__ out_others, float* __restrict__ pix_state, size_t plane, uint8_t* hits /* written by phase 0: neither const nor restrict */,
                  float4* __restrict__ zero, size_t zero_n)
 {
     __shared__ FwdBatch batches[4];
@@ -233,6 +234,14 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
     const uint2 range = ranges[tile];
+    // phase 0: the sub-block cull bits of this tile's list, by all four waves.  Workgroup scope is enough: the waves of a
+    // workgroup share the CU's write-through vector cache, so after the release / barrier / acquire the plain loads
+    // below see the stores (an agent-scope fence would write back the XCD's whole L2 from every workgroup)
+    cull_tile_list(range, (float)(tx * GS2D_TILE), (float)(ty * GS2D_TILE), point_list, rec,
+                   reinterpret_cast<uint32_t*>(hits));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const uint8_t* qrow = wb.ql[row];
 
@@ -904,7 +913,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
 namespace gs2d {
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
-                      const float* bg, float* out_color, float* out_others, float* pix_state, const uint8_t* hits, int use_sa,
+                      const float* bg, float* out_color, float* out_others, float* pix_state, uint8_t* hits, int use_sa,
                       float4* zero, size_t zero_n, hipStream_t s)
 {
     const int gx = (W + GS2D_TILE - 1) / GS2D_TILE, gy = (H + GS2D_TILE - 1) / GS2D_TILE;

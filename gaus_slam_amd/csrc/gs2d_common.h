@@ -75,7 +75,7 @@ static inline BinLayout bin_layout(int R, bool det = false)
     size_t o = 0;
     const size_t r = (size_t)(R > 0 ? R : 1);
     L.point_list = o; o = gs2d_align_up(o + 4 * r, 256);
-    // cull_kernel -> both blend kernels: per instance and quadrant, the 4-bit sub-block cull mask (one byte each)
+    // phase 0 of blend_fwd -> both blend kernels: per instance and quadrant, the 4-bit sub-block cull mask (one byte each)
     L.hits = o; o = gs2d_align_up(o + 4 * r, 256);
     L.keys = o; o = gs2d_align_up(o + 8 * r, 256);
     L.vals_alt = o; o = gs2d_align_up(o + 4 * r, 256);
@@ -196,11 +196,11 @@ bool launch_bin_by_tile(int R, int tiles, int nbits, const uint64_t* keys_in, co
 void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt,
                             uint32_t* vals_alt, int packed, int write_keys, hipStream_t s);
 void launch_tile_ranges(int R, const uint64_t* keys, uint2* ranges, int tiles, hipStream_t s);
-// hits[4 * i + q]: low nibble = the 4x4 sub-blocks of quadrant q that instance i of the sorted list can touch
-void launch_cull(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec, uint8_t* hits, hipStream_t s);
-// also clears zero_n float4 at `zero` (the backward's gradient accumulator) with its idle store slots
+// Writes hits[4 * i + q] (low nibble = the 4x4 sub-blocks of quadrant q that instance i of the sorted list can touch, see
+// gs2d_cull.h) for every instance, then blends.  Also clears zero_n float4 at `zero` (the backward's gradient accumulator)
+// with its idle store slots.
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
-                      const float* bg, float* out_color, float* out_others, float* pix_state, const uint8_t* hits, int use_sa,
+                      const float* bg, float* out_color, float* out_others, float* pix_state, uint8_t* hits, int use_sa,
                       float4* zero, size_t zero_n, hipStream_t s);
 // det_slots != nullptr selects the deterministic variant: no atomics, per-(instance, quadrant) partial records
 // (GS2D_GRAD_FLOATS floats each, R * 4 of them, zero-initialised by the caller) that launch_det_reduce then sums

@@ -1,17 +1,20 @@
-// Per-instance sub-block cull: ONE pass over the depth-sorted instance list that decides, for every (Gaussian, tile)
+// Per-instance sub-block cull: ONE pass over a tile's depth-sorted instance list that decides, for every (Gaussian, tile)
 // instance, which of the tile's sixteen 4x4 pixel sub-blocks the splat can reach with alpha >= 1/255.  Both blend
 // kernels build their per-sub-block queues from these bits, so neither evaluates a cull test nor loads the record of a
-// splat that touches nothing in its quadrant.  (Round 1 ran the test inside blend_fwd, once per quadrant wave, i.e. the
-// conic of every instance was rebuilt four times: about a third of that kernel's vector instructions.)
+// splat that touches nothing in its quadrant.  (Round 1 ran the test once per quadrant wave, i.e. the conic of every
+// instance was rebuilt four times: about a third of blend_fwd's vector instructions.)  The pass runs as phase 0 of
+// blend_fwd_kernel (each workgroup culls its own tile's list, then blends it): as a kernel of its own it cost 30 us plus
+// a launch boundary, inline its latency stalls are filled by other workgroups' blending (about 20 us).
 //
 // Culling never changes a result: a culled (sub-block, splat) pair is one whose every pixel the reference would
 // `continue` past (alpha < 1/255, forward.cu:385-387 / backward.cu:319-320); tests: bit-exact n_contrib on a stress scene.
+#pragma once
 #include "gs2d_common.h"
 
 namespace {
 
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float cull_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float cull_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 // Bit layout of the result (shared with the blend kernels): byte q = quadrant q of the tile (q = 2*(y>=8) + (x>=8), the
 // wave that owns it), bit r of that byte's low nibble = 4x4 sub-block r of the quadrant (r = 2*(y%8>=4) + (x%8>=4), the
@@ -85,7 +88,7 @@ __device__ __forceinline__ uint32_t splat_touch_mask16(const float4 q0, const fl
     const float Pz = (fabsf(Az) + fabsf(Bz)) * 7.5f + fabsf(Cz);
     const float margin = 1e-4f * (Px * Px + Py * Py + c * (Pz * Pz));
     if (!(margin < 1e30f)) return 0xFFFFu;  // overflow / NaN in the coefficients: keep (below this every term of F is finite)
-    const float nhx = -0.5f * fast_rcp(Fxx), nhy = -0.5f * fast_rcp(Fyy);
+    const float nhx = -0.5f * cull_rcp(Fxx), nhy = -0.5f * cull_rcp(Fyy);
     // the 8 horizontal and 8 vertical edge lines of the sub-blocks (local coordinate e of line i: -7.5 + 4 (i/2) + 3 (i%2)):
     //   F(t, e) = Fxx t^2 + hb t + hc   (horizontal, y = e)      F(e, t) = Fyy t^2 + vb t + vc   (vertical, x = e)
     float hb[8], hc[8], ht[8], vb[8], vc[8], vt[8];
@@ -116,22 +119,18 @@ __device__ __forceinline__ uint32_t splat_touch_mask16(const float4 q0, const fl
     return m;
 }
 
-// One workgroup per tile walks the tile's sorted segment, thread t takes instances t, t+256, ...; the two dependent
-// gathers of the NEXT instance (id, then 52 bytes of its record) are issued before the ~700 instructions of the current
-// one, so only a wave's first gather is exposed.  hits[i] = the 16 sub-block bits of instance i, spread over four bytes
-// (byte q = nibble of quadrant q).  (Tried and dropped: 1024-thread workgroups, -25 %; a flat one-instance-per-thread grid
-// fed by per-instance tile ids from the depth sort, -30 %: every wave then pays both gather latencies for one instance.)
+
 #ifndef GS2D_CULL_T
 #define GS2D_CULL_T 256
 #endif
-__global__ void __launch_bounds__(GS2D_CULL_T)
-cull_kernel(int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-            const float4* __restrict__ rec, uint32_t* __restrict__ hits)
+// The tile's sorted segment walked by 256 threads, thread t takes instances t, t+256, ...; the two dependent gathers of
+// the NEXT instance (id, then 52 bytes of its record) are issued before the ~700 instructions of the current one, so only
+// a wave's first gather is exposed.  hits[i] = the 16 sub-block bits of instance i, spread over four bytes (byte q = nibble
+// of quadrant q).  (Tried and dropped: 1024-thread workgroups, -25 %; a flat one-instance-per-thread grid fed by
+// per-instance tile ids from the depth sort, -30 %: every wave then pays both gather latencies for one instance.)
+__device__ __forceinline__ void cull_tile_list(const uint2 range, float tx0, float ty0, const uint32_t* __restrict__ point_list,
+                                               const float4* __restrict__ rec, uint32_t* __restrict__ hits)
 {
-    const int tile = blockIdx.x;
-    if (tile >= ntiles) return;
-    const uint2 range = ranges[tile];
-    const float tx0 = (float)((tile % gx) * GS2D_TILE), ty0 = (float)((tile / gx) * GS2D_TILE);
     uint32_t i = range.x + threadIdx.x;
     if (i >= range.y) return;
     const uint32_t last = range.y - 1;
@@ -156,14 +155,3 @@ cull_kernel(int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t
 }
 
 }  // namespace
-
-namespace gs2d {
-
-void launch_cull(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec, uint8_t* hits, hipStream_t s)
-{
-    const int gx = (W + GS2D_TILE - 1) / GS2D_TILE, gy = (H + GS2D_TILE - 1) / GS2D_TILE;
-    hipLaunchKernelGGL(cull_kernel, dim3(gx * gy), dim3(GS2D_CULL_T), 0, s, gx, gx * gy, ranges, point_list, rec,
-                       reinterpret_cast<uint32_t*>(hits));
-}
-
-}  // namespace gs2d

@@ -247,7 +247,8 @@ void gs2d_binning_layout(int R, size_t offsets[2]);
 void gs2d_image_layout(int width, int height, size_t offsets[2]);
 
 /* Optional per-stage device timing with hipEvents recorded on the launch stream (bench.py's roofline leg).
- * ms[9] = preprocess, scan, duplicate, sort, ranges, blend_fwd, blend_bwd, preprocess_bwd, cull; -1 = not recorded. */
+ * ms[9] = preprocess, scan, duplicate, sort, ranges, blend_fwd, blend_bwd, preprocess_bwd, cull; -1 = not recorded
+ * (cull: always -1, the sub-block cull runs as the first phase of blend_fwd). */
 void gs2d_stage_timing_enable(int on);
 int gs2d_stage_timing_read(float ms[9]);
 
