@@ -86,7 +86,8 @@ static inline BinLayout bin_layout(int R, bool det = false)
     const size_t bin_elems = (size_t)GS2D_BIN_MAX_TILES * ((r + GS2D_BIN_ITEMS - 1) / GS2D_BIN_ITEMS);
     const size_t cap_elems = L.hist_elems > bin_elems ? L.hist_elems : bin_elems;
     const size_t scan_blk = (cap_elems + GS2D_SCAN_ITEMS - 1) / GS2D_SCAN_ITEMS;
-    L.hist = o; o = gs2d_align_up(o + 4 * (cap_elems + scan_blk + 64), 256);
+    // (+ GS2D_BIN_MAX_TILES: the per-tile totals of the binning pass sit behind its counters)
+    L.hist = o; o = gs2d_align_up(o + 4 * (cap_elems + scan_blk + 64 + GS2D_BIN_MAX_TILES), 256);
     L.det_inv = o; L.det_slots = o;
     if (det) {
         o = gs2d_align_up(o + 4 * r, 256);
