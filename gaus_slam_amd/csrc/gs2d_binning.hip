@@ -121,14 +121,16 @@ duplicate_kernel(int P, const ushort4* __restrict__ rect, const float* __restric
     // 256 Gaussians, scan_blocksums_kernel turned those into exclusive block offsets, and this workgroup (the same 256
     // Gaussians) adds its own inclusive scan -- no separate scan-apply launch.
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t mine = idx < P ? tiles_touched[idx] : 0u;
+    const int ci = min(idx, P - 1);
+    const uint32_t mine = idx < P ? tiles_touched[ci] : 0u;
+    // everything the emit loop needs is requested before the workgroup scan, whose two barriers then hide the latency
+    const ushort4 r = rect[ci];
+    const uint32_t dbits = __float_as_uint(depths[ci]);
     const uint32_t incl = block_offsets[blockIdx.x] + block_incl_scan(mine, nullptr);
     if (idx >= P) return;
     point_offsets[idx] = incl;  // inclusive offsets, as the reference's InclusiveSum leaves them
     if (mine == 0u) return;
     uint32_t off = incl - mine;
-    const ushort4 r = rect[idx];
-    const uint32_t dbits = __float_as_uint(depths[idx]);
     for (uint32_t y = r.y; y < r.w; y++)
         for (uint32_t x = r.x; x < r.z; x++) {
             const uint64_t key = ((uint64_t)(y * (uint32_t)gx + x) << 32) | dbits;
