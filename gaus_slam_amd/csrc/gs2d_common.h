@@ -146,11 +146,19 @@ __device__ __forceinline__ Gs2dFootprint gs2d_footprint(const float4 q0, const f
     const float f0 = rho_max * inv, f2 = -inv;
     f.cx = f0 * (q0.x * q2.x + q0.y * q2.y) + f2 * (q0.z * q2.z);
     f.cy = f0 * (q1.x * q2.x + q1.y * q2.y) + f2 * (q1.z * q2.z);
-    const float hx = f.cx * f.cx - (f0 * (q0.x * q0.x + q0.y * q0.y) + f2 * (q0.z * q0.z));
-    const float hy = f.cy * f.cy - (f0 * (q1.x * q1.x + q1.y * q1.y) + f2 * (q1.z * q1.z));
+    // Half extents.  The reference's form (forward.cu:139-146) is cx^2 - <Tu,Tu>/<Tw,Tw> with <a,b> = rho (a.x b.x + a.y b.y)
+    // - a.z b.z: two numbers of the size of cx^2 that differ by the extent^2 -- at x = 1000 px and an extent of 1 px that
+    // is a 10^6 : 1 cancellation.  The same quantity without it (Lagrange's identity for this metric):
+    //   <Tu,Tw>^2 - <Tu,Tu><Tw,Tw> = rho [ c.x^2 + c.y^2 - rho c.z^2 ],  c = Tu x Tw,
+    // whose terms are the 2x2 minors of (Tu, Tw), each a mild difference of products.
+    const float ux = q0.y * q2.z - q0.z * q2.y, uy = q0.z * q2.x - q0.x * q2.z, uz = q0.x * q2.y - q0.y * q2.x;
+    const float vx = q1.y * q2.z - q1.z * q2.y, vy = q1.z * q2.x - q1.x * q2.z, vz = q1.x * q2.y - q1.y * q2.x;
+    const float k = rho_max * (inv * inv);
+    const float hx = k * ((ux * ux + uy * uy) - rho_max * (uz * uz));
+    const float hy = k * ((vx * vx + vy * vy) - rho_max * (vz * vz));
     if (!(hx == hx) || !(hy == hy)) return f;
     f.ex = __builtin_amdgcn_sqrtf(fmaxf(hx, 0.f)); f.ey = __builtin_amdgcn_sqrtf(fmaxf(hy, 0.f));
-    f.mx = 0.5f + 0.02f * f.ex + 1e-4f * fabsf(f.cx); f.my = 0.5f + 0.02f * f.ey + 1e-4f * fabsf(f.cy);
+    f.mx = 0.1f + 0.002f * f.ex + 1e-4f * fabsf(f.cx); f.my = 0.1f + 0.002f * f.ey + 1e-4f * fabsf(f.cy);
     f.kind = 1;
     return f;
 }

@@ -146,3 +146,20 @@ def test_footprint_edge_cases(oracle):
     for k in ("color", "allmap"):
         np.testing.assert_array_equal(ot[k].view(np.uint32), o[k].view(np.uint32), err_msg=k)
         np.testing.assert_array_equal(ht[k].view(np.uint32), hr[k].view(np.uint32), err_msg=k)
+
+
+@pytest.mark.parametrize("P,W,H,regime", [(600000, 1200, 680, "tracking"), (2000000, 1168, 876, "mapping"),
+                                          (300000, 3840, 2160, "mapping")])
+def test_footprint_large_images_bit_identical(P, W, H, regime):
+    """Centres thousands of pixels from the origin (where a cancellation-prone bound would be least accurate) and tile
+    counts on both sides of the single-pass binning limit: forward outputs bit-identical between the modes, lists a
+    subsequence."""
+    sc = util.make_scene(P, W, H, seed=1, regime=regime)
+    hr = util.hip_forward(sc, binning="reference")
+    ht = util.hip_forward(sc, binning="footprint")
+    np.testing.assert_array_equal(ht["radii"], hr["radii"])
+    for k in ("color", "allmap", "final_T"):
+        np.testing.assert_array_equal(ht[k].view(np.uint32), hr[k].view(np.uint32), err_msg=k)
+    _assert_subsequence(hr, ht, hr["ranges"].shape[0])
+    assert ht["num_rendered"] < hr["num_rendered"]
+    print(f"{W}x{H}: reference {hr['num_rendered']}, footprint {ht['num_rendered']}")
