@@ -215,6 +215,8 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
                 ba.bucket.pack(g)
             opt.step(ba.bucket.flat)
 
+    # N > 1: chunked/overlapped or whole-bucket all-reduce, whichever is faster on this node (untimed setup, before the warm-up)
+    tuned = ba.autotune(keyframes) if (world > 1 and kpg == 1 and not args.adam) else {}
     elapsed = timed(one_step, args.steps, args.warmup, world, dev)
     frames = args.steps * world * kpg
     ms_per_step = elapsed / args.steps * 1e3
@@ -318,7 +320,9 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
                                f"use_sa={use_sa}, {kpg} keyframe{'s' if kpg > 1 else ''} per GPU" + (f" on {args.streams} HIP streams" if kpg > 1 and args.streams > 1 else ""), "num_rendered": R, "num_rendered_reference_rects": R_ref, "visible": visible,
                    "step": "op forward+backward" + (" + all-reduce of the [P,13] grad bucket" if world > 1 else "")
                            + (f" + {args.adam} Adam (lr=0)" if args.adam else ""),
-                   "parallelism": f"keyframe-sharded x{world}", "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4)},
+                   "parallelism": f"keyframe-sharded x{world}", "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
+                   "allreduce_chunks": ba.overlap_chunks if world > 1 else None,
+                   "allreduce_chunks_tuning_ms": {str(k): round(v, 4) for k, v in tuned.items()} or None},
         "roofline": roofline, "cpu_baseline": cpu_baseline,
     }
 

@@ -199,6 +199,32 @@ class KeyframeShardedBA:
                 v.div_(self.world_size)
         return self.bucket.views
 
+    def autotune(self, keyframes, candidates=(1, 2, 4), reps=3):
+        """Pick overlap_chunks by measurement on the machine at hand: one whole-bucket all-reduce after the backward (1) against
+        chunked reductions overlapped with the per-Gaussian stage.  Chunking hides at most the length of that stage (26 us at
+        500k Gaussians) and pays one collective latency per extra chunk, so which one wins depends on the interconnect and
+        the bucket size.  Every candidate runs `reps` steps after one untimed step; ranks agree on the choice through a MAX
+        all-reduce of their times.  Returns {candidate: ms per step}; a no-op (returns {}) for world size 1."""
+        if self.world_size == 1 or not self.direct_grads or not self.params["means3D"].is_cuda:
+            return {}
+        import time
+        dev = self.params["means3D"].device
+        times = {}
+        for c in candidates:
+            self.overlap_chunks = max(1, int(c))
+            self.step(keyframes)
+            torch.cuda.synchronize(dev)
+            dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                self.step(keyframes)
+            torch.cuda.synchronize(dev)
+            t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            times[int(c)] = float(t.item())
+        self.overlap_chunks = min(times, key=lambda k: (times[k], k))  # identical on every rank
+        return times
+
     def step(self, keyframes):
         """One BA step over a batch of keyframes (len == world_size in the bench; ragged batches allowed: ranks
         without a keyframe contribute zeros).  Returns the reduced bucket views (name -> [P,k])."""

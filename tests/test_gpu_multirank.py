@@ -57,6 +57,15 @@ for chunks in (4, 1):
         res["alias"] = np.array([params[n].grad is not None and params[n].grad.data_ptr() == ba.bucket.views[n].data_ptr() for n in names])
         fr = ba.gather_frame_params(torch.arange(9, dtype=torch.float32, device=dev) + 100 * rank)
         res["frames"] = fr.cpu().numpy()
+# autotune: every rank ends with the same choice, and a step after it still reduces correctly
+params, bat = make(4)
+times = bat.autotune([0, 1], candidates=(1, 2), reps=1)
+pick = torch.tensor([bat.overlap_chunks], device=dev)
+dist.all_reduce(pick, op=dist.ReduceOp.MAX)
+res["tuned_same"] = np.array([int(pick.item()) == bat.overlap_chunks and set(times) == {1, 2} and bat.overlap_chunks in (1, 2)])
+bat.step([0, 1])
+torch.cuda.synchronize()
+res["flat_tuned"] = bat.bucket.flat.cpu().numpy()
 # serial reference on this rank: both keyframes, plain autograd, summed
 params, ba1 = make(1)
 tot = None
@@ -87,5 +96,7 @@ def test_two_ranks_real_rasterizer_direct_grads_chunked_allreduce():
     assert scale > 0
     assert np.abs(d["flat4"] - d["serial"]).max() <= 1e-4 * scale  # float atomics: equal up to summation order
     assert np.abs(d["flat1"] - d["serial"]).max() <= 1e-4 * scale
+    assert d["tuned_same"].all()
+    assert np.abs(d["flat_tuned"] - d["serial"]).max() <= 1e-4 * scale
     assert d["alias"].all(), d["alias"]
     assert d["frames"].shape == (2, 9) and d["frames"][1, 0] == 100.0 and d["frames"][0, 8] == 8.0
