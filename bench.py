@@ -343,7 +343,9 @@ def slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world):
         settings = gs_render.settings_from_camera(sc["cam"], dev, use_sa=use_sa)
         p = {k: sc[k].to(dev) for k in names}
         w2c = random_w2c(np.random.default_rng(1), 2.0, 0.05).to(dev).requires_grad_(True)
-        opt = torch.optim.Adam([w2c], lr=0.0)  # lr = 0: the pose (and so the workload) stays fixed, the update runs
+        # lr = 0: the pose (and so the workload) stays fixed, the update runs; fused=True: one kernel instead of torch's
+        # seven foreach launches for this single 4x4 tensor (33 us of a 0.66-ms iteration)
+        opt = torch.optim.Adam([w2c], lr=0.0, fused=True)
 
         def one_step():
             opt.zero_grad(set_to_none=True)

@@ -373,8 +373,9 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
     }
     (void)colors_precomp; (void)transMat_precomp; (void)scale_modifier;
     hipStream_t s = (hipStream_t)stream;
-    // the pose gradient is accumulated by the preprocess stage(s): cleared once, by the call that runs the blend stage
-    if (dL_dpose != nullptr && (stages & 1) != 0)
+    // The pose gradient is accumulated by the preprocess stage(s) and cleared once, by the call that runs the blend stage:
+    // inside blend_bwd_kernel when that kernel runs (one launch less on the tracking loop's critical path), else by a memset.
+    if (dL_dpose != nullptr && (stages & 1) != 0 && (P <= 0 || R <= 0 || g_deterministic.load() != 0))
         GS2D_CHECK(hipMemsetAsync(dL_dpose, 0, sizeof(float) * 12, s), "memset dL_dpose");
     if (P <= 0) return 0;
     if (g_begin < 0 || g_end > P || g_begin > g_end) return fail_msg("bad Gaussian range");
@@ -397,7 +398,7 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         if (R > 0) {
             g_timer.begin(ST_BLEND_BWD, s);
             gs2d::launch_blend_bwd(width, height, ranges, point_list, rec, background, pix_state, hits, dL_dpix, dL_depths,
-                                   grad_rec, use_sa, nullptr, s);
+                                   grad_rec, use_sa, nullptr, dL_dpose, s);
             g_timer.end(ST_BLEND_BWD, s);
             GS2D_STAGE("blend_bwd");
         }
@@ -411,7 +412,7 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         if (R > 0) {
             GS2D_CHECK(hipMemsetAsync(det_slots, 0, sizeof(float) * GS2D_GRAD_FLOATS * 4 * (size_t)R, s), "memset det_slots");
             gs2d::launch_blend_bwd(width, height, ranges, point_list, rec, background, pix_state, hits, dL_dpix, dL_depths,
-                                   grad_rec, use_sa, det_slots, s);
+                                   grad_rec, use_sa, det_slots, nullptr, s);
         }
         gs2d::launch_det_reduce(P, R, width, height, ranges, point_list, (const ushort4*)(geom_buffer + GL.rect),
                                 (const uint32_t*)(geom_buffer + GL.tiles_touched),

@@ -211,11 +211,12 @@ void launch_tile_ranges(int R, const uint64_t* keys, uint2* ranges, int tiles, h
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
                       const float* bg, float* out_color, float* out_others, float* pix_state, uint8_t* hits, int use_sa,
                       float4* zero, size_t zero_n, hipStream_t s);
+// clear12 (optional): 12 floats zeroed by the kernel (the pose-gradient sums the next stage accumulates into).
 // det_slots != nullptr selects the deterministic variant: no atomics, per-(instance, quadrant) partial records
 // (GS2D_GRAD_FLOATS floats each, R * 4 of them, zero-initialised by the caller) that launch_det_reduce then sums
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
                       const float* bg, const float* pix_state, const uint8_t* hits, const float* dL_dpix,
-                      const float* dL_dothers, float* grad_rec, int use_sa, float* det_slots, hipStream_t s);
+                      const float* dL_dothers, float* grad_rec, int use_sa, float* det_slots, float* clear12, hipStream_t s);
 // deterministic mode: inv[unsorted instance] = sorted position, then grad_rec[g] = sum of g's slots in a fixed order
 void launch_det_reduce(int P, int R, int W, int H, const uint2* ranges, const uint32_t* point_list, const ushort4* rect,
                        const uint32_t* tiles_touched, const uint32_t* point_offsets, const uint8_t* hits,
