@@ -2,9 +2,10 @@
 //
 // Semantics: RAST/cuda_rasterizer/forward.cu:258-467 and backward.cu:143-463 of the reference.
 // Design (gfx950, wave64):
-//   * one workgroup per 16x16 tile, 4 fully independent waves (no workgroup barrier anywhere), each wave owns an 8x8
+//   * one workgroup per 16x16 tile, 4 independent waves (no workgroup barrier in the blend loops), each wave owns an 8x8
 //     pixel quadrant and each of its 16-lane DPP rows a 4x4 sub-block;
-//   * which splats can touch which sub-block is decided once per instance by cull_kernel (gs2d_cull.hip); both kernels
+//   * which splats can touch which sub-block is decided once per instance, in phase 0 of the forward kernel (the four
+//     waves cull their tile's list together, gs2d_cull.h; one workgroup barrier, then they part ways); both kernels
 //     read those bits, fetch only the touching splats' packed records (one lane per record), stage them compacted in
 //     wave-private LDS in batches of 64 and give every row its own depth-ordered queue of slot numbers (a byte list in
 //     LDS): each loop trip the four rows composite four different splats, records read back as per-row LDS broadcasts,
@@ -141,7 +142,7 @@ __device__ __forceinline__ int pop_back(uint64_t& m)
 // ------------------------------------------------------------------------------------------- forward
 // One wave per 8x8 pixel quadrant, 4 independent waves per 16x16 tile; inside the wave each 16-lane DPP row owns
 // one 4x4 sub-block.  The tile's depth-sorted list is read in 64-instance chunks; the cull bits of this quadrant
-// (cull_kernel, gs2d_cull.hip) say which splats touch which sub-block, so only touching splats are fetched and staged,
+// (phase 0 below, gs2d_cull.h) say which splats touch which sub-block, so only touching splats are fetched and staged,
 // compacted, in wave-private LDS until the 64 slots of a BATCH are full.  Each sub-block (= DPP row) then gets its own
 // depth-ordered QUEUE of slot numbers -- a byte list in LDS, built once per batch with ballot + mbcnt -- and every loop
 // trip row r reads the next entry of ITS queue and that splat's record (per-row address, 5 x ds_read_b128,

@@ -13,7 +13,7 @@ for sub in ('sq','sq2'):
     for f in glob.glob(f'gpurun_out/prof_{tag}/{sub}/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
             n=r['Kernel_Name']
-            for k in ('blend_fwd_kernel','blend_bwd_kernel','cull_kernel','tile_depth_sort_kernel'):
+            for k in ('blend_fwd_kernel','blend_bwd_kernel','tile_depth_sort_kernel'):
                 if k in n: acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in acc.items():
         print(k, {c: round(sum(x)/len(x)) for c,x in v.items()})

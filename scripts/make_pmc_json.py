@@ -10,7 +10,7 @@ import os
 import sys
 
 d = sys.argv[1]
-STAGE = {"blend_fwd_kernel": "blend_fwd", "blend_bwd_kernel": "blend_bwd", "cull_kernel": "cull", "preprocess_fwd_kernel": "preprocess",
+STAGE = {"blend_fwd_kernel": "blend_fwd", "blend_bwd_kernel": "blend_bwd", "preprocess_fwd_kernel": "preprocess",
          "preprocess_bwd_kernel": "preprocess_bwd", "bin_hist_kernel": "sort", "bin_scatter_kernel": "sort", "tile_depth_sort_kernel": "sort",
          "scan_reduce_kernel": "sort", "scan_apply_kernel": "sort", "duplicate_kernel": "duplicate"}
 
@@ -35,7 +35,7 @@ out_t = {k: int(v) for k, v in traffic.items()}
 out_t["_note"] = ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes of `bench.py --steps 3`), "
                   "FETCH_SIZE doubled per the gfx950 guide (MI355X_MICROARCH.md, HBM); sort = bin_hist + scans + bin_scatter + tile_depth_sort")
 out_v = {}
-for k in ("blend_fwd_kernel", "blend_bwd_kernel", "cull_kernel"):
+for k in ("blend_fwd_kernel", "blend_bwd_kernel"):
     if k in sq:
         out_v[STAGE[k]] = {"valu_wave_insts": int(sq[k].get("SQ_INSTS_VALU", 0)), "salu_wave_insts": int(sq[k].get("SQ_INSTS_SALU", 0)),
                            "wave_quad_cycles": int(sq[k].get("SQ_WAVE_CYCLES", 0)), "wait_any": int(sq[k].get("SQ_WAIT_ANY", 0)),
