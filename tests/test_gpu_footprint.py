@@ -117,6 +117,12 @@ def test_footprint_full_size_bit_identical_and_smaller():
     _assert_subsequence(hr, ht, hr["ranges"].shape[0])
     assert ht["num_rendered"] < 0.9 * hr["num_rendered"]
     print(f"instances: reference {hr['num_rendered']}, footprint {ht['num_rendered']}")
+    # the gradients agree up to the order of the float atomics (all ten upstream channels live)
+    dc, da = util.make_upstream_grads(W, H, seed=21, channels=(0, 1, 2, 3, 4, 5, 6))
+    dc = (dc * W * H).numpy(); da = (da * W * H).numpy()
+    gr, gt = util.hip_backward(hr, dc, da), util.hip_backward(ht, dc, da)
+    for k in GRADS:
+        assert util.grad_err(gt[k], gr[k]) <= 2e-5, k
 
 
 def test_footprint_edge_cases(oracle):
