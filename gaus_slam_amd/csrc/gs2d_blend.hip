@@ -174,28 +174,36 @@ __device__ __forceinline__ int xcd_tile(int block, int ntiles)
 // single-wave issue rate and with every latency exposed (scripts/dev/wave_profile.py: the last 40 % of the kernel ran
 // with less than half of the waves).  Priority by remaining work makes the laggard the favourite: the waves of a SIMD
 // stay together and finish together.  Placement only -- results do not depend on it.
-#ifndef GS2D_PRIO_SHIFT
-#define GS2D_PRIO_SHIFT 1  // level boundaries at remaining = total >> (SHIFT * k), k = 1..3 (1: 1/2, 1/4, 1/8)
+// Level boundaries, SHIFT > 0: geometric, at remaining = total >> (SHIFT * k), k = 1..3 (1: 1/2, 1/4, 1/8) -- only the END
+// of the lists is synchronised, and the last level (where the arbiter is back to oldest-first) is short; SHIFT == 0:
+// uniform quarters.  Measured on the shipped kernels: the backward wants the geometric levels (0.314 vs 0.320 ms with
+// quarters; 1/4, 1/16, 1/64: 0.333), the forward -- whose waves start staggered by their cull phase -- the quarters
+// (0.151 vs 0.156 ms); no priorities at all: 0.173 / 0.351 ms.
+#ifndef GS2D_FWD_PRIO_SHIFT
+#define GS2D_FWD_PRIO_SHIFT 0
+#endif
+#ifndef GS2D_BWD_PRIO_SHIFT
+#define GS2D_BWD_PRIO_SHIFT 1
 #endif
 #ifndef GS2D_NO_SETPRIO
+template <int SHIFT>
 __device__ __forceinline__ void prio_by_remaining(uint32_t remaining, uint32_t total)
 {
-    // Geometric level boundaries: only the END of the lists has to be synchronised (a spread early on costs nothing), and
-    // inside the last level the arbiter is back to oldest-first, so that level is kept short.
-#if GS2D_PRIO_SHIFT == 0
-    const uint32_t q = remaining * 4u;  // uniform quarters
-    if (q > total * 3u) __builtin_amdgcn_s_setprio(3);
-    else if (q > total * 2u) __builtin_amdgcn_s_setprio(2);
-    else if (q > total) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
-#else
-    if (remaining > (total >> GS2D_PRIO_SHIFT)) __builtin_amdgcn_s_setprio(3);
-    else if (remaining > (total >> (2 * GS2D_PRIO_SHIFT))) __builtin_amdgcn_s_setprio(2);
-    else if (remaining > (total >> (3 * GS2D_PRIO_SHIFT))) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
-#endif
+    if (SHIFT == 0) {
+        const uint32_t q = remaining * 4u;
+        if (q > total * 3u) __builtin_amdgcn_s_setprio(3);
+        else if (q > total * 2u) __builtin_amdgcn_s_setprio(2);
+        else if (q > total) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    } else {
+        if (remaining > (total >> SHIFT)) __builtin_amdgcn_s_setprio(3);
+        else if (remaining > (total >> (2 * SHIFT))) __builtin_amdgcn_s_setprio(2);
+        else if (remaining > (total >> (3 * SHIFT))) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
 }
 #else
+template <int SHIFT>
 __device__ __forceinline__ void prio_by_remaining(uint32_t, uint32_t) {}
 #endif
 
@@ -266,7 +274,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     uint32_t pf_id = point_list[min(next_chunk + lane, last_i)];
     for (;;) {
         if (__ballot(!done) == 0) break;
-        prio_by_remaining(range.y - min(next_chunk, range.y), range.y - range.x);
+        prio_by_remaining<GS2D_FWD_PRIO_SHIFT>(range.y - min(next_chunk, range.y), range.y - range.x);
         int fill = 0;
         GS2D_PROF_STAGE_BEGIN();
         wave_lds_sync();  // previous batch fully consumed before it is overwritten
@@ -647,7 +655,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
 #endif
     for (;;) {
         int fill = 0;
-        prio_by_remaining((uint32_t)(chunk + 1), (max_last + 63u) / 64u);
+        prio_by_remaining<GS2D_BWD_PRIO_SHIFT>((uint32_t)(chunk + 1), (max_last + 63u) / 64u);
         GS2D_PROF_STAGE_BEGIN();
         wave_lds_sync();  // previous batch fully consumed before it is overwritten
         for (;;) {
