@@ -255,7 +255,7 @@ def is_deterministic():
 def set_reference_binning(on=True):
     """gs2d_set_reference_binning: one instance for every tile of the reference's 3-sigma square (num_rendered and the
     sorted lists bit-identical to the reference's) instead of only the tiles inside the splat's footprint bound (default;
-    same outputs, about a quarter fewer instances).  Process-wide; applies to the next forward."""
+    same outputs, about a fifth fewer instances).  Process-wide; applies to the next forward."""
     _lib.lib().gs2d_set_reference_binning(int(bool(on)))
 
 

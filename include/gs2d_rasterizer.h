@@ -180,7 +180,7 @@ int gs2d_get_deterministic(void);
  * the opacity and follows the projected ellipse; every instance left out is one whose pixels the reference would all
  * `continue` past (forward.cu:385-387), so colours, depth maps and gradients are unchanged (the forward outputs are
  * bit-identical between the two modes, tests/test_gpu_footprint.py) while the sort and both blend passes handle about a
- * quarter fewer instances.  Consequences of the default: num_rendered, tiles_touched and the per-tile lists are the
+ * fifth fewer instances.  Consequences of the default: num_rendered, tiles_touched and the per-tile lists are the
  * reference's minus those instances (the lists are ordered subsequences of the reference's).  radii are the reference's.
  * gs2d_set_reference_binning(1) switches to the reference's rectangles: then num_rendered and the sorted lists are
  * bit-identical to the reference's (what the binning parity tests compare against the oracle).
