@@ -54,8 +54,9 @@ class GradBucket:
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1) or g1 <= g0:
             return
         if dist.get_backend(group) == "nccl" or not self.flat.is_cuda:
-            dev = self.flat.device if self.flat.is_cuda else None
-            with dist._coalescing_manager(group=group, device=dev, async_ops=True) as cm:
+            # no `device` argument: the slices are recorded and issued as ONE allreduce_coalesced when the context closes
+            # (c10d's fast path; with a device it would additionally wrap them in start/end-coalescing calls)
+            with dist._coalescing_manager(group=group, async_ops=True) as cm:
                 for v in self.views.values():
                     dist.all_reduce(v[g0:g1], op=dist.ReduceOp.SUM, group=group)
             self._pending.append(cm)
