@@ -288,6 +288,7 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     if (!bin) return fail_msg("binning allocation failed");
     uint32_t* point_list = (uint32_t*)(bin + BL.point_list);
     uint8_t* hits = (uint8_t*)(bin + BL.hits);
+    uint8_t* hits4 = (uint8_t*)(bin + BL.hits4);
     uint64_t* keys = (uint64_t*)(bin + BL.keys);
     uint32_t* vals_alt = (uint32_t*)(bin + BL.vals_alt);
     uint64_t* keys_alt = (uint64_t*)(bin + BL.keys_alt);
@@ -332,7 +333,7 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
         GS2D_STAGE("tile depth sort");
     }
     g_timer.begin(ST_BLEND_FWD, s);
-    gs2d::launch_blend_fwd(width, height, ranges, point_list, rec, background, out_color, out_others, pix_state, hits,
+    gs2d::launch_blend_fwd(width, height, ranges, point_list, rec, background, out_color, out_others, pix_state, hits, hits4,
                            use_sa, (float4*)(geom + GL.grad_rec), (size_t)P * (GS2D_GRAD_FLOATS / 4), s);
     g_clean.add(geom);
     g_timer.end(ST_BLEND_FWD, s);
@@ -388,7 +389,7 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
     const uint8_t* clamped = (const uint8_t*)(geom_buffer + GL.clamped);
     float* grad_rec = (float*)(geom_buffer + GL.grad_rec);
     const uint32_t* point_list = (const uint32_t*)(binning_buffer + BL.point_list);
-    const uint8_t* hits = (const uint8_t*)(binning_buffer + BL.hits);
+    const uint8_t* hits = (const uint8_t*)(binning_buffer + BL.hits4);  // the backward reads the row bits (one byte per quadrant)
     const uint2* ranges = (const uint2*)(img_buffer + IL.ranges);
     const float* pix_state = (const float*)(img_buffer + IL.pix);
 

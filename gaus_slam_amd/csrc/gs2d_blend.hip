@@ -152,8 +152,9 @@ __device__ __forceinline__ int pop_back(uint64_t& m)
 // only the loop counter (round 1 popped 64-bit bit-queues with ~65 scalar instructions per trip).
 struct FwdBatch {
     float4 q[GS2D_REC_F4][64];  // staged records, SoA by quarter
-    uint8_t ql[4][64];          // per-row queues: slot numbers in depth order
+    uint8_t ql[16][64];         // per-group queues: slot numbers in depth order, 255 = end
     uint32_t tail[4];           // the pipeline reads up to two entries past a full queue (values unused)
+    uint16_t tm[64];            // group bits of the staged splats
 };
 
 // XCD-aware workgroup -> tile mapping.  Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own
@@ -226,7 +227,7 @@ template <bool USE_SA>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS2D_FWD_WAVES_PER_EU, GS2D_FWD_WAVES_PER_EU)))
 blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
-                 float* __restrict__ out_others, float* __restrict__ pix_state, size_t plane, uint8_t* hits /* written by phase 0: neither const nor restrict */,
+                 float* __restrict__ out_others, float* __restrict__ pix_state, size_t plane, uint8_t* hits /* written by phase 0: neither const nor restrict */, uint8_t* hits4,
                  float4* __restrict__ zero, size_t zero_n)
 {
     __shared__ FwdBatch batches[4];
@@ -236,18 +237,18 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     FwdBatch& wb = batches[wave];
     const int qx0 = tx * GS2D_TILE + (wave & 1) * 8, qy0 = ty * GS2D_TILE + (wave >> 1) * 8;
-    const int row = lane >> 4, li = lane & 15;                       // DPP row = 4x4 sub-block
-    const int row8 = row * 8;
-    const int lx = (row & 1) * 4 + (li & 3), ly = (row >> 1) * 4 + (li >> 2);  // position inside the quadrant
+    const int row = lane >> 2, li = lane & 3;                        // DPP quad = 2x2 pixel group, 16 groups per quadrant
+    const int lx = (row & 3) * 2 + (li & 1), ly = (row >> 2) * 2 + (li >> 1);  // position inside the quadrant
     const int px = qx0 + lx, py = qy0 + ly;
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
     const uint2 range = ranges[tile];
+    const uint16_t* hits16 = reinterpret_cast<const uint16_t*>(hits);  // [instance][quadrant]: 16 group bits
     // phase 0: the sub-block cull bits of this tile's list, by all four waves.  Workgroup scope is enough: the waves of a
     // workgroup share the CU's write-through vector cache, so after the release / barrier / acquire the plain loads
     // below see the stores (an agent-scope fence would write back the XCD's whole L2 from every workgroup)
     cull_tile_list(range, (float)(tx * GS2D_TILE), (float)(ty * GS2D_TILE), point_list, rec,
-                   reinterpret_cast<uint32_t*>(hits));
+                   reinterpret_cast<uint64_t*>(hits), reinterpret_cast<uint32_t*>(hits4));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -270,7 +271,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     // the cull bits and the Gaussian id of chunk `next_chunk` are always in flight one chunk ahead (unconditional loads,
     // index clamped to the list), so that the record gather is the only serial memory round trip of a chunk
     const uint32_t last_i = range.y > range.x ? range.y - 1u : range.x;
-    uint32_t pf_tm = hits[(size_t)min(next_chunk + lane, last_i) * 4 + wave];
+    uint32_t pf_tm = hits16[(size_t)min(next_chunk + lane, last_i) * 4 + wave];
     uint32_t pf_id = point_list[min(next_chunk + lane, last_i)];
     for (;;) {
         if (__ballot(!done) == 0) break;
@@ -286,7 +287,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                 cbase = next_chunk; next_chunk += 64;
                 tm = cbase + lane < range.y ? pf_tm : 0u;
                 id = pf_id;
-                pf_tm = hits[(size_t)min(next_chunk + lane, last_i) * 4 + wave];
+                pf_tm = hits16[(size_t)min(next_chunk + lane, last_i) * 4 + wave];
                 pf_id = point_list[min(next_chunk + lane, last_i)];
             }
             const uint64_t tb = __ballot(tm != 0u);
@@ -298,8 +299,9 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                 const float4* rp = rec + (size_t)id * GS2D_REC_F4;
                 const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
                 float4 r4 = rp[4];
-                r4.w = __uint_as_float(((cbase - range.x + lane) << 4) | tm);  // list position + cull bits ride in the free slot
+                r4.w = __uint_as_float(cbase - range.x + lane);  // the list position rides in the free slot
                 wb.q[0][slot] = r0; wb.q[1][slot] = r1; wb.q[2][slot] = r2; wb.q[3][slot] = r3; wb.q[4][slot] = r4;
+                wb.tm[slot] = (uint16_t)tm;
             }
             if (fill + c > 64) { carry_tm = take ? 0u : tm; carry_id = id; carry_base = cbase; carry = true; fill = 64; break; }
             fill += c;
@@ -307,16 +309,17 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
         }
         if (fill == 0) break;  // list exhausted
         wave_lds_sync();
-        // the four row queues: slot numbers of the splats whose bit r is set, in slot (= depth) order
-        const uint32_t nib = lane < fill ? __float_as_uint(wb.q[4][lane].w) : 0u;
-        const uint64_t m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u), m2 = __ballot(nib & 4u), m3 = __ballot(nib & 8u);
-        if (nib & 1u) wb.ql[0][rank_below(m0)] = (uint8_t)lane;
-        if (nib & 2u) wb.ql[1][rank_below(m1)] = (uint8_t)lane;
-        if (nib & 4u) wb.ql[2][rank_below(m2)] = (uint8_t)lane;
-        if (nib & 8u) wb.ql[3][rank_below(m3)] = (uint8_t)lane;
-        const int len0 = __popcll(m0), len1 = __popcll(m1), len2 = __popcll(m2), len3 = __popcll(m3);
-        const int trips = max(max(len0, len1), max(len2, len3));  // >= 1: every staged splat touches some row
-        const int mylen = row_select(row8, len0, len1, len2, len3);
+        // the sixteen group queues: slot numbers of the splats whose bit r is set, in slot (= depth) order, ended by 255
+        reinterpret_cast<uint4*>(&wb.ql[0][0])[lane] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        const uint32_t nib = lane < fill ? (uint32_t)wb.tm[lane] : 0u;
+        int trips = 0;  // the longest queue; >= 1: every staged splat touches some group
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const bool in_r = ((nib >> r) & 1u) != 0u;
+            const uint64_t mr = __ballot(in_r);
+            if (in_r) wb.ql[r][rank_below(mr)] = (uint8_t)lane;
+            trips = max(trips, (int)__popcll(mr));
+        }
         wave_lds_sync();
         GS2D_PROF_STAGE_END();
         // software pipeline: the records of the NEXT trip are fetched from LDS while the current ones are evaluated (queue
@@ -328,6 +331,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
 #define GS2D_FWD_STEP(C0, C1, C2, C3, C4, N0_, N1_, N2_, N3_, N4_, JN, JNN)                                          \
         {                                                                                                            \
             GS2D_PROF_TRIP();                                                                                        \
+            const bool live_ = JNN < 64u; /* JNN still holds THIS trip's queue entry; 255: this group's queue is exhausted */ \
             N0_ = wb.q[0][JN & 63]; N1_ = wb.q[1][JN & 63]; N2_ = wb.q[2][JN & 63]; N3_ = wb.q[3][JN & 63];          \
             N4_ = wb.q[4][JN & 63];                                                                                  \
             JNN = qrow[t + 2];                                                                                       \
@@ -335,11 +339,11 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
             bool ok;                                                                                                 \
             fwd_eval(C0, C1, C2, pxf, pyf, alpha, depth, ok);                                                        \
             const float test_T = T * (1 - alpha);                                                                    \
-            const bool pass = ok && !done && t < mylen; /* t >= mylen: this row's queue is exhausted */              \
+            const bool pass = ok && !done && live_;                                                                  \
             const bool stop = pass && test_T < 0.0001f;                                                              \
             done = done || stop;                                                                                     \
             if (pass && !stop) {                                                                                     \
-                const uint32_t contributor = (__float_as_uint(C4.w) >> 4) + 1u; /* list position + 1 */             \
+                const uint32_t contributor = __float_as_uint(C4.w) + 1u; /* list position + 1 */                    \
                 const float w = alpha * T;                                                                           \
                 if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }                            \
                 if (USE_SA) { /* forward.cu:405-416 */                                                               \
@@ -400,6 +404,11 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     }
     clear_share(zero, zero_n);
 }
+
+// The backward keeps one queue per 4x4 sub-block (16-lane DPP row): finer queues would cut its trips too, but every
+// (group, splat) pair costs 13 LDS float atomics and those run at about half a lane per clock per CU -- with sixteen
+// 2x2 groups the kernel measured 0.59 ms instead of 0.31 ms.  Its four row bits per quadrant are the ORs of the forward's
+// group bits, written next to them by phase 0 of the forward (hits4, rows_from_groups in gs2d_cull.h).
 
 // ------------------------------------------------------------------------------------------ backward
 template <int CTRL>
@@ -573,7 +582,9 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     const uint2 range = ranges[tile];
     const size_t HW = (size_t)H * W;
     const size_t pix = (size_t)W * py + px;
-    const size_t si = (size_t)tile * GS2D_TILE_PIX + threadIdx.x;
+    // the forward keeps its per-pixel state in ITS lane order (2x2 pixel groups, blend_fwd_kernel)
+    const int flx = (row & 1) * 4 + (li & 3), fly = (row >> 1) * 4 + (li >> 2);
+    const size_t si = (size_t)tile * GS2D_TILE_PIX + wave * 64 + ((fly >> 1) * 4 + (flx >> 1)) * 4 + (fly & 1) * 2 + (flx & 1);
 
     // backward.cu:197-248
     const float T_final = inside ? pix_state[PS_TFINAL * plane + si] : 0.f;
@@ -924,18 +935,18 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
 namespace gs2d {
 
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
-                      const float* bg, float* out_color, float* out_others, float* pix_state, uint8_t* hits, int use_sa,
-                      float4* zero, size_t zero_n, hipStream_t s)
+                      const float* bg, float* out_color, float* out_others, float* pix_state, uint8_t* hits, uint8_t* hits4,
+                      int use_sa, float4* zero, size_t zero_n, hipStream_t s)
 {
     const int gx = (W + GS2D_TILE - 1) / GS2D_TILE, gy = (H + GS2D_TILE - 1) / GS2D_TILE;
     const size_t plane = (size_t)gx * gy * GS2D_TILE_PIX;
     const int grid = GS2D_XCDS * ((gx * gy + GS2D_XCDS - 1) / GS2D_XCDS);
     if (use_sa)
         hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, W, H, gx, gx * gy, ranges, point_list, rec,
-                           bg, out_color, out_others, pix_state, plane, hits, zero, zero_n);
+                           bg, out_color, out_others, pix_state, plane, hits, hits4, zero, zero_n);
     else
         hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, W, H, gx, gx * gy, ranges, point_list, rec,
-                           bg, out_color, out_others, pix_state, plane, hits, zero, zero_n);
+                           bg, out_color, out_others, pix_state, plane, hits, hits4, zero, zero_n);
 }
 
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,

@@ -33,7 +33,7 @@ struct GeomLayout {
     size_t depths, tiles_touched, point_offsets, rec, clamped, scan_tmp, grad_rec, rect, total;
 };
 struct BinLayout {
-    size_t point_list, hits, keys, vals_alt, keys_alt, hist, det_inv, det_slots, total;
+    size_t point_list, hits, hits4, keys, vals_alt, keys_alt, hist, det_inv, det_slots, total;
     size_t hist_elems;
 };
 struct ImgLayout {
@@ -75,8 +75,11 @@ static inline BinLayout bin_layout(int R, bool det = false)
     size_t o = 0;
     const size_t r = (size_t)(R > 0 ? R : 1);
     L.point_list = o; o = gs2d_align_up(o + 4 * r, 256);
-    // phase 0 of blend_fwd -> both blend kernels: per instance and quadrant, the 4-bit sub-block cull mask (one byte each)
-    L.hits = o; o = gs2d_align_up(o + 4 * r, 256);
+    // phase 0 of blend_fwd -> both blend kernels: per instance and quadrant, the 16 group bits of the cull test (u16 each)
+    L.hits = o; o = gs2d_align_up(o + 8 * r, 256);
+    // the same bits ORed down to the four 4x4 sub-blocks of each quadrant (one byte per quadrant): what the backward's
+    // four row queues are built from
+    L.hits4 = o; o = gs2d_align_up(o + 4 * r, 256);
     L.keys = o; o = gs2d_align_up(o + 8 * r, 256);
     L.vals_alt = o; o = gs2d_align_up(o + 4 * r, 256);
     L.keys_alt = o; o = gs2d_align_up(o + 8 * r, 256);
@@ -205,12 +208,12 @@ bool launch_bin_by_tile(int R, int tiles, int nbits, const uint64_t* keys_in, co
 void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt,
                             uint32_t* vals_alt, int packed, int write_keys, hipStream_t s);
 void launch_tile_ranges(int R, const uint64_t* keys, uint2* ranges, int tiles, hipStream_t s);
-// Writes hits[4 * i + q] (low nibble = the 4x4 sub-blocks of quadrant q that instance i of the sorted list can touch, see
+// Writes hits (u16[4 * i + q] = the 2x2 pixel groups of quadrant q that instance i of the sorted list can touch, see
 // gs2d_cull.h) for every instance, then blends.  Also clears zero_n float4 at `zero` (the backward's gradient accumulator)
 // with its idle store slots.
 void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
-                      const float* bg, float* out_color, float* out_others, float* pix_state, uint8_t* hits, int use_sa,
-                      float4* zero, size_t zero_n, hipStream_t s);
+                      const float* bg, float* out_color, float* out_others, float* pix_state, uint8_t* hits, uint8_t* hits4,
+                      int use_sa, float4* zero, size_t zero_n, hipStream_t s);
 // clear12 (optional): 12 floats zeroed by the kernel (the pose-gradient sums the next stage accumulates into).
 // det_slots != nullptr selects the deterministic variant: no atomics, per-(instance, quadrant) partial records
 // (GS2D_GRAD_FLOATS floats each, R * 4 of them, zero-initialised by the caller) that launch_det_reduce then sums

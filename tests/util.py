@@ -28,15 +28,15 @@ def oracle_forward(orc, sc, use_sa=True, bg=(0.0, 0.0, 0.0), shs=None, sh_degree
 
 
 def pix_index_map(W, H):
-    """state index (tile*256 + quadrant*64 + subblock*16 + (y%4)*4 + x%4) for every pixel, as [H,W] int64 (see
-    include/gs2d_rasterizer.h)."""
+    """state index (tile*256 + quadrant*64 + group*4 + (y%2)*2 + x%2, group = the 2x2 pixel group of the 8x8 quadrant,
+    row-major 4x4) for every pixel, as [H,W] int64 (see include/gs2d_rasterizer.h)."""
     gx = (W + TILE - 1) // TILE
     ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
     tile = (ys // TILE) * gx + (xs // TILE)
     ly, lx = ys % TILE, xs % TILE
     quad = (ly // 8) * 2 + (lx // 8)
-    sub = ((ly % 8) // 4) * 2 + (lx % 8) // 4
-    return tile * 256 + quad * 64 + sub * 16 + (ly % 4) * 4 + (lx % 4)
+    group = ((ly % 8) // 2) * 4 + (lx % 8) // 2
+    return tile * 256 + quad * 64 + group * 4 + (ly % 2) * 2 + (lx % 2)
 
 
 def hip_forward(sc, use_sa=True, bg=(0.0, 0.0, 0.0), shs=None, sh_degree=0, transMat_precomp=None, scale_modifier=1.0,
