@@ -55,7 +55,7 @@ def stage_bytes(P, R, HW):
         "sort": 24 * R,                        # one read + one write of the 12-B pairs (a 6-pass LSD sort moves 6x)
         "ranges": 8 * R,
         "cull": 0,                             # (runs inside blend_fwd since round 2: id + 52 B of the record in, 4 B out)
-        "blend_fwd": 60 * R + 84 * R + 68 * HW,  # cull phase (id + 52 B of the record in, 4 B of bits out) + 4-B id + 80-B
+        "blend_fwd": 68 * R + 84 * R + 68 * HW,  # cull phase (id + 52 B of the record in, 8 + 4 B of bits out) + 4-B id + 80-B
                                                # record per instance; 40 B images + 28 B state per pixel
         "blend_bwd": 84 * R + 68 * HW + 72 * P,  # gather + per-pixel grads/state + accumulator write-back
         "preprocess_bwd": 152 * P + 80 * P,

@@ -239,8 +239,8 @@ size_t gs2d_binning_bytes(int R);
  * u8[3P].  Binning: [0] point_list u32[R], [1] sorted keys u64[R].
  * Image: [0] ranges u32[tiles][2], [1] pixel state f32/u32[7][tiles*256]
  * (planes: T_final, M1, M2, median depth, depth std, last contributor, median
- * contributor; element index = tile*256 + quadrant*64 + subblock*16 + (y%4)*4 + (x%4) with
- * quadrant = (y/8)*2 + (x/8) and subblock = ((y%8)/4)*2 + (x%8)/4 for pixel (x,y) inside its 16x16 tile).
+ * contributor; element index = tile*256 + quadrant*64 + group*4 + (y%2)*2 + (x%2) with
+ * quadrant = (y/8)*2 + (x/8) and group = ((y%8)/2)*4 + (x%8)/2 for pixel (x,y) inside its 16x16 tile).
  */
 void gs2d_geometry_layout(int P, size_t offsets[5]);
 void gs2d_binning_layout(int R, size_t offsets[2]);

@@ -15,7 +15,8 @@ o = util.oracle_forward(orc, sc, use_sa=True)
 h = util.hip_forward(sc, use_sa=True)
 R = h["num_rendered"]
 binning = h["buffers"][1].cpu().numpy()
-off = ((4 * R + 255) // 256) * 256  # BinLayout: point_list, then hits
+al = lambda n: (n + 255) // 256 * 256
+off = al(4 * R) + al(8 * R)  # BinLayout: point_list, group bits (8 B), then the row bits (4 B, one byte per quadrant)
 hits = np.frombuffer(binning.tobytes()[off:off + 4 * R], dtype=np.uint32)
 L = C.CDLL("scripts/dev/exact_bits.so")
 ex = np.zeros(R, np.uint32)

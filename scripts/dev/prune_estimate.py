@@ -18,7 +18,7 @@ fw = util.hip_forward(sc, debug=True)
 R = fw["num_rendered"]
 b = fw["buffers"][1].cpu().numpy()
 off = (4 * R + 255) // 256 * 256
-hits = np.frombuffer(b.tobytes()[off:off + 4 * R], dtype=np.uint32)
+hits = np.frombuffer(b.tobytes()[off:off + 8 * R], dtype=np.uint64)  # 64 group bits per instance
 pl, rng = fw["point_list"].astype(np.int64), fw["ranges"].astype(np.int64)
 gx = (W + 15) // 16
 tile = np.repeat(np.arange(len(rng)), rng[:, 1] - rng[:, 0])
