@@ -3,12 +3,14 @@
 // Semantics: RAST/cuda_rasterizer/forward.cu:258-467 and backward.cu:143-463 of the reference.
 // Design (gfx950, wave64):
 //   * one workgroup per 16x16 tile, 4 independent waves (no workgroup barrier in the blend loops), each wave owns an 8x8
-//     pixel quadrant and each of its 16-lane DPP rows a 4x4 sub-block;
-//   * which splats can touch which sub-block is decided once per instance, in phase 0 of the forward kernel (the four
+//     pixel quadrant; a forward wave splits it into sixteen 2x2 pixel GROUPS (one per DPP quad), a backward wave into four
+//     4x4 sub-blocks (one per 16-lane DPP row) -- finer groups mean fewer loop trips, but every (group, splat) pair of the
+//     backward ends in 13 LDS float atomics, which sixteen groups would serialise (measured: 0.59 vs 0.31 ms);
+//   * which splats can touch which group is decided once per instance, in phase 0 of the forward kernel (the four
 //     waves cull their tile's list together, gs2d_cull.h; one workgroup barrier, then they part ways); both kernels
 //     read those bits, fetch only the touching splats' packed records (one lane per record), stage them compacted in
-//     wave-private LDS in batches of 64 and give every row its own depth-ordered queue of slot numbers (a byte list in
-//     LDS): each loop trip the four rows composite four different splats, records read back as per-row LDS broadcasts,
+//     wave-private LDS in batches and give every group its own depth-ordered queue of slot numbers (a byte list in
+//     LDS): each loop trip the groups composite different splats, records read back as per-group LDS broadcasts,
 //     prefetched one trip ahead;
 //   * backward: per-(pixel,splat) gradients are summed over the 16 lanes of a row with a 16-value DPP butterfly, added
 //     into per-splat accumulators in wave-private LDS (ds_add_f32) and flushed to the Gaussian's gradient record once
@@ -140,14 +142,14 @@ __device__ __forceinline__ int pop_back(uint64_t& m)
 }
 
 // ------------------------------------------------------------------------------------------- forward
-// One wave per 8x8 pixel quadrant, 4 independent waves per 16x16 tile; inside the wave each 16-lane DPP row owns
-// one 4x4 sub-block.  The tile's depth-sorted list is read in 64-instance chunks; the cull bits of this quadrant
-// (phase 0 below, gs2d_cull.h) say which splats touch which sub-block, so only touching splats are fetched and staged,
-// compacted, in wave-private LDS until the 64 slots of a BATCH are full.  Each sub-block (= DPP row) then gets its own
+// One wave per 8x8 pixel quadrant, 4 independent waves per 16x16 tile; inside the wave each DPP quad (4 lanes) owns
+// one 2x2 pixel group.  The tile's depth-sorted list is read in 64-instance chunks; the cull bits of this quadrant
+// (phase 0 below, gs2d_cull.h) say which splats touch which group, so only touching splats are fetched and staged,
+// compacted, in wave-private LDS until the 64 slots of a BATCH are full.  Each group then gets its own
 // depth-ordered QUEUE of slot numbers -- a byte list in LDS, built once per batch with ballot + mbcnt -- and every loop
-// trip row r reads the next entry of ITS queue and that splat's record (per-row address, 5 x ds_read_b128,
-// software-pipelined one trip ahead; the queue entries two trips ahead), so the four rows composite four different
-// splats at once: per-pixel order is untouched (a splat that touches several sub-blocks sits in several queues), the
+// trip group g reads the next entry of ITS queue and that splat's record (per-group address, 5 x ds_read_b128,
+// software-pipelined one trip ahead; the queue entries two trips ahead), so the sixteen groups composite up to sixteen
+// different splats at once: per-pixel order is untouched (a splat that touches several groups sits in several queues), the
 // trip count is the LONGEST queue instead of the whole list, the VALU executes only per-pixel math and the scalar unit
 // only the loop counter (round 1 popped 64-bit bit-queues with ~65 scalar instructions per trip).
 struct FwdBatch {
