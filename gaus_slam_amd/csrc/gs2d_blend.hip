@@ -546,6 +546,11 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
 // and the low-pass mean2D components) into a slot of its own, det_slots[(instance * 4 + quadrant) * 20 ...], LDS adds are
 // issued row by row (no two lanes of one instruction meet on an address), and det_reduce_kernel sums a Gaussian's slots
 // in a fixed order (its tiles row-major, quadrants 0..3).  Two runs give bit-identical gradients.
+// Adding a row's 13 totals to its splat's accumulators: LDS float atomics (rows may share a splat).  The LDS index unit
+// is busy 81 % of the kernel (rocprofv3 SQ_LDS_IDX_ACTIVE), but the obvious relief -- a plain read-add-write on the trips
+// where the four rows hold four different splats (wave-uniform test) -- measured slower (0.338 vs 0.329 ms): the read's
+// latency enters the trip's dependency chain and the test costs four v_readlane.
+#define GS2D_BWD_LDS_ACCUM(JJ, V) if ((V) != 0.f) GS2D_EXP_LDSADD(&wb.acc[((JJ) & 63) * NACC + acc_comp], V);
 #define GS2D_ACC 13
 #define GS2D_ACC_DET 18
 template <int NACC>
@@ -855,8 +860,9 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                     if (DET) { /* one row at a time: lanes of different rows may hold the same (splat, component) */ \
                         _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++)                                              \
                             if (row == r_ && acc_comp >= 0 && tot != 0.f) atomicAdd(&wb.acc[(J & 63) * NACC + acc_comp], tot); \
-                    } else if (acc_comp >= 0 && tot != 0.f) GS2D_EXP_LDSADD(&wb.acc[(J & 63) * NACC + acc_comp], tot); \
-                    else if (ANY_DN && tot != 0.f)                                                                    \
+                    } else if (acc_comp >= 0) {                                                                       \
+                        GS2D_BWD_LDS_ACCUM(J, tot)                                                                    \
+                    } else if (ANY_DN && tot != 0.f)                                                                  \
                         atomicAdd(grad_rec + (size_t)__float_as_uint(cc.w) * GS2D_GRAD_FLOATS + (slot - 9), tot);     \
                     if (__ballot(d_t != 0.f) != 0) {                                                                  \
                         const float g_mx = row_sum_to_lane15(d_t * d0);                                               \
