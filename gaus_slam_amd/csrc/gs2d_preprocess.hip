@@ -614,7 +614,10 @@ void launch_preprocess_bwd(int first, int P, int D, int M, const float* means3D,
     int grid = (P - first + 255) / 256;
     // every workgroup ends with 12 atomics on the same pose-gradient words (1954 workgroups at 500k Gaussians: +14 us);
     // two Gaussians per thread halve that without starving the memory system of waves
-    if (dL_dpose != nullptr && grid > 1024) grid = max(1024, (grid + 1) / 2);
+#ifndef GS2D_POSE_GPT
+#define GS2D_POSE_GPT 2  // Gaussians per thread with a pose
+#endif
+    if (dL_dpose != nullptr && grid > 1024) grid = max(1024 / (GS2D_POSE_GPT / 2), (grid + GS2D_POSE_GPT - 1) / GS2D_POSE_GPT);
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(grid), dim3(256), 0, s, first, P, D, M, means3D, rec, radii, shs,
                        clamped, scales, rotations, cam, grad_rec, dL_dtransMat, dL_dnormal, dL_dcolor, dL_dopacity,
                        dL_dsh, dL_dmean2D, dL_dmean3D, dL_dscale, dL_drot, pose_Rt, pose_q, dL_dpose);
