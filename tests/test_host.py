@@ -103,3 +103,20 @@ def test_camera_matches_reference_formulas():
     P = cam.projmatrix.t()  # true projection: row 3 = (0,0,1,0) so clip w = view z
     assert torch.allclose(P[3], torch.tensor([0.0, 0.0, 1.0, 0.0]))
     assert P[0, 0] == pytest.approx(2 * 525.0 / W) and P[0, 2] == pytest.approx(-(W - 2 * 319.5) / W)
+
+
+def test_pixel_state_index_map_is_a_bijection():
+    """tests/util.pix_index_map mirrors the forward's lane order (2x2 pixel groups): every pixel of a tile-aligned image
+    gets its own slot and whole 64-slot runs belong to one 8x8 quadrant."""
+    import numpy as np
+    from tests import util
+    W, H = 48, 32
+    idx = util.pix_index_map(W, H)
+    assert sorted(idx.ravel().tolist()) == list(range(W * H))
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    quad_of_pixel = (ys // 8) * (W // 8) + xs // 8
+    for run in range(W * H // 64):
+        assert len(set(quad_of_pixel[(idx // 64) == run].tolist())) == 1
+    # the four lanes of a group are a 2x2 pixel block
+    g0 = np.argwhere((idx // 4) == 5)
+    assert g0[:, 0].max() - g0[:, 0].min() == 1 and g0[:, 1].max() - g0[:, 1].min() == 1
