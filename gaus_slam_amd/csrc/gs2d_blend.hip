@@ -536,7 +536,7 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
 // r,g,b,id -- the normal is fetched from global memory only by waves that carry normal gradients) and 13 gradient
 // accumulators per splat (3 colour, 9 dT, 1 opacity).  The gradient atomics are the backward's scarcest resource
 // (scripts/dev/atomic_bench.hip: the kernel's former atomic stream alone takes ~360 us on the whole chip), so every
-// (row, splat) contribution is first added into LDS (ds_add_f32) and each touched splat of the batch is flushed to its
+// (row, splat) contribution is first added into LDS (GS2D_BWD_LDS_ACCUM below) and each touched splat of the batch is flushed to its
 // global record ONCE per (quadrant, batch) -- about half as many global atomics, three quarters of a workgroup's LDS
 // budget (29.6 KB, 5 workgroups per CU).
 //
@@ -544,13 +544,34 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
 // gradients run-to-run non-deterministic, backward.cu:441-460): no global atomic at all.  Every (instance, quadrant) pair
 // is accumulated by exactly one wave in exactly one batch, so that wave STORES its 18 sums (the 13 above plus the normal
 // and the low-pass mean2D components) into a slot of its own, det_slots[(instance * 4 + quadrant) * 20 ...], LDS adds are
-// issued row by row (no two lanes of one instruction meet on an address), and det_reduce_kernel sums a Gaussian's slots
+// plain read-add-writes issued row by row (no two lanes of one instruction meet on an address), and det_reduce_kernel sums a Gaussian's slots
 // in a fixed order (its tiles row-major, quadrants 0..3).  Two runs give bit-identical gradients.
-// Adding a row's 13 totals to its splat's accumulators: LDS float atomics (rows may share a splat).  The LDS index unit
-// is busy 81 % of the kernel (rocprofv3 SQ_LDS_IDX_ACTIVE), but the obvious relief -- a plain read-add-write on the trips
-// where the four rows hold four different splats (wave-uniform test) -- measured slower (0.338 vs 0.329 ms): the read's
-// latency enters the trip's dependency chain and the test costs four v_readlane.
+// Adding a row's 13 totals to its splat's accumulators.  An LDS float atomic is the slowest instruction of the kernel:
+// scripts/dev/lds_atomic_rate.hip measures ds_add_f32 at ~137 LDS clocks per wave instruction with 52 active lanes
+// (ds_add_u32: 4.4, ds_write_b32: 7.1), and the LDS index unit was busy 81 % of the kernel (SQ_LDS_IDX_ACTIVE).  So a
+// trip READS its accumulator first thing (the latency hides behind the trip's ~250 instructions) and, when the four rows
+// hold four different splats (wave-uniform test on four v_readlane), finishes with a plain store of old + total; only
+// trips in which two rows meet on a splat fall back to the atomic.  0.329 -> 0.306 ms.  Measured and dropped: reading
+// the accumulator at the end of the trip (0.338 ms, the latency enters the dependency chain), merging twin rows' totals
+// with v_permlane16/32_swap so that no trip needs the atomic (0.330 ms, +4 spills), and a per-row instead of
+// wave-uniform fallback (no change).
+#define GS2D_BWD_ACC_PRE(JJ)                                                                                            \
+    const int ai_ = ((JJ) & 63) * NACC + (acc_comp < 0 ? 0 : acc_comp);                                                 \
+    const float acc_old_ = wb.acc[ai_];                                                                                 \
+    const uint32_t ja_ = __builtin_amdgcn_readlane(JJ, 0), jb0_ = __builtin_amdgcn_readlane(JJ, 16),                    \
+                   jc0_ = __builtin_amdgcn_readlane(JJ, 32), jd0_ = __builtin_amdgcn_readlane(JJ, 48);                  \
+    /* exhausted rows (255) add nothing: make them differ from each other */                                            \
+    const uint32_t jb_ = jb0_ < 64u ? jb0_ : 256u, jc_ = jc0_ < 64u ? jc0_ : 257u, jd_ = jd0_ < 64u ? jd0_ : 258u;      \
+    const bool clash_ = ja_ == jb_ || ja_ == jc_ || ja_ == jd_ || jb_ == jc_ || jb_ == jd_ || jc_ == jd_;
+#ifdef GS2D_EXPERIMENT
 #define GS2D_BWD_LDS_ACCUM(JJ, V) if ((V) != 0.f) GS2D_EXP_LDSADD(&wb.acc[((JJ) & 63) * NACC + acc_comp], V);
+#else
+#define GS2D_BWD_LDS_ACCUM(JJ, V)                                                                                       \
+    if ((V) != 0.f) {                                                                                                   \
+        if (clash_) atomicAdd(&wb.acc[ai_], V);                                                                         \
+        else wb.acc[ai_] = acc_old_ + (V);                                                                              \
+    }
+#endif
 #define GS2D_ACC 13
 #define GS2D_ACC_DET 18
 template <int NACC>
@@ -746,6 +767,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
             const uint32_t contributor = wb.pn[J & 63] >> 4; /* list position, 0-based, as in backward.cu:285 */      \
             bool active = J < 64u && contributor < last_contributor; /* J == 255: queue exhausted; outside: last = 0 */ \
             if (__ballot(active) != 0) {                                                                              \
+                GS2D_BWD_ACC_PRE(J)                                                                                   \
                 /* Part A (all lanes): same geometry / alpha as the forward */                                        \
                 const float k0 = fmaf(pxf, G2.x, -G0.x), k1 = fmaf(pxf, G2.y, -G0.y), k2 = fmaf(pxf, G2.z, -G0.z);    \
                 const float l0 = fmaf(pyf, G2.x, -G1.x), l1 = fmaf(pyf, G2.y, -G1.y), l2 = fmaf(pyf, G2.z, -G1.z);    \
@@ -859,7 +881,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                     /* LDS float atomics run at a few lanes per clock: rows/components that sum to +-0 skip them */    \
                     if (DET) { /* one row at a time: lanes of different rows may hold the same (splat, component) */ \
                         _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++)                                              \
-                            if (row == r_ && acc_comp >= 0 && tot != 0.f) atomicAdd(&wb.acc[(J & 63) * NACC + acc_comp], tot); \
+                            if (row == r_ && acc_comp >= 0 && tot != 0.f) wb.acc[(J & 63) * NACC + acc_comp] += tot; \
                     } else if (acc_comp >= 0) {                                                                       \
                         GS2D_BWD_LDS_ACCUM(J, tot)                                                                    \
                     } else if (ANY_DN && tot != 0.f)                                                                  \
@@ -870,7 +892,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                         if (DET) {                                                                                    \
                             _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++)                                          \
                                 if (row == r_ && li == 15 && (g_mx != 0.f || g_my != 0.f)) {                          \
-                                    atomicAdd(&wb.acc[(J & 63) * NACC + 16], g_mx); atomicAdd(&wb.acc[(J & 63) * NACC + 17], g_my); \
+                                    wb.acc[(J & 63) * NACC + 16] += g_mx; wb.acc[(J & 63) * NACC + 17] += g_my;   \
                                 }                                                                                     \
                         } else if (li == 15 && (g_mx != 0.f || g_my != 0.f)) {                                        \
                             float* dst = grad_rec + (size_t)__float_as_uint(cc.w) * GS2D_GRAD_FLOATS;                 \
