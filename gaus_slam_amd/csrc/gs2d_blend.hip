@@ -558,11 +558,10 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
 #define GS2D_BWD_ACC_PRE(JJ)                                                                                            \
     const int ai_ = ((JJ) & 63) * NACC + (acc_comp < 0 ? 0 : acc_comp);                                                 \
     const float acc_old_ = wb.acc[ai_];                                                                                 \
-    const uint32_t ja_ = __builtin_amdgcn_readlane(JJ, 0), jb0_ = __builtin_amdgcn_readlane(JJ, 16),                    \
-                   jc0_ = __builtin_amdgcn_readlane(JJ, 32), jd0_ = __builtin_amdgcn_readlane(JJ, 48);                  \
-    /* exhausted rows (255) add nothing: make them differ from each other */                                            \
-    const uint32_t jb_ = jb0_ < 64u ? jb0_ : 256u, jc_ = jc0_ < 64u ? jc0_ : 257u, jd_ = jd0_ < 64u ? jd0_ : 258u;      \
-    const bool clash_ = ja_ == jb_ || ja_ == jc_ || ja_ == jd_ || jb_ == jc_ || jb_ == jd_ || jc_ == jd_;
+    const uint32_t ja_ = __builtin_amdgcn_readlane(JJ, 0), jb_ = __builtin_amdgcn_readlane(JJ, 16),                     \
+                   jc_ = __builtin_amdgcn_readlane(JJ, 32), jd_ = __builtin_amdgcn_readlane(JJ, 48);                    \
+    /* an exhausted row reads its own end marker (252 + row), so two of those never look like a shared splat */         \
+    const bool clash_ = min(min(min(ja_ ^ jb_, ja_ ^ jc_), min(ja_ ^ jd_, jb_ ^ jc_)), min(jb_ ^ jd_, jc_ ^ jd_)) == 0u;
 #ifdef GS2D_EXPERIMENT
 #define GS2D_BWD_LDS_ACCUM(JJ, V) if ((V) != 0.f) GS2D_EXP_LDSADD(&wb.acc[((JJ) & 63) * NACC + acc_comp], V);
 #else
@@ -745,7 +744,9 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
         const uint32_t nib = lane >= 64 - fill ? wb.pn[lane] : 0u;
         const uint64_t m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u), m2 = __ballot(nib & 4u), m3 = __ballot(nib & 8u);
         const int len0 = __popcll(m0), len1 = __popcll(m1), len2 = __popcll(m2), len3 = __popcll(m3);
-        reinterpret_cast<uint32_t*>(wb.ql)[lane] = 0xFFFFFFFFu;  // every entry past a queue's end reads 255 = "exhausted"
+        // every entry past a queue's end reads 252 + row = "exhausted" (any value >= 64; distinct per row for the
+        // shared-splat test of GS2D_BWD_ACC_PRE)
+        reinterpret_cast<uint32_t*>(wb.ql)[lane] = 0x01010101u * (0xFCu | (uint32_t)(lane >> 4));
         if (nib & 1u) wb.ql[0][len0 - 1 - rank_below(m0)] = (uint8_t)lane;
         if (nib & 2u) wb.ql[1][len1 - 1 - rank_below(m1)] = (uint8_t)lane;
         if (nib & 4u) wb.ql[2][len2 - 1 - rank_below(m2)] = (uint8_t)lane;
@@ -765,7 +766,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
             N0_ = wb.q[0][JN & 63]; N1_ = wb.q[1][JN & 63]; N2_ = wb.q[2][JN & 63];                                   \
             const float4 cc = wb.q[3][J & 63]; /* r, g, b, id */                                                      \
             const uint32_t contributor = wb.pn[J & 63] >> 4; /* list position, 0-based, as in backward.cu:285 */      \
-            bool active = J < 64u && contributor < last_contributor; /* J == 255: queue exhausted; outside: last = 0 */ \
+            bool active = J < 64u && contributor < last_contributor; /* J >= 252: queue exhausted; outside: last = 0 */ \
             if (__ballot(active) != 0) {                                                                              \
                 GS2D_BWD_ACC_PRE(J)                                                                                   \
                 /* Part A (all lanes): same geometry / alpha as the forward */                                        \
