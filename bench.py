@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--keyframes-per-gpu", type=int, default=1, help="keyframes each rank renders per step (default 1 = the "
                     "headline metric); rendered one after the other unless --streams 2")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams a rank spreads its keyframes over (ba_shard.KeyframeShardedBA)")
+    ap.add_argument("--rccl-one-rank", action="store_true", help="rehearsal on one GPU: create a ONE-rank RCCL communicator and "
+                    "run the N > 1 code path (bucket, chunked all-reduce, autotune, collective timing) through the real library; "
+                    "not a performance number")
     ap.add_argument("--json-out", default=None, help="also write the JSON line to this file (profiles/...)")
     args = ap.parse_args()
 
@@ -102,6 +105,12 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
                "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+    if args.rccl_one_rank:
+        global _ONE_RANK_RCCL
+        _ONE_RANK_RCCL = True
+        from gaus_slam_amd import ba_shard as _bs
+        _bs.MIN_COLLECTIVE_WORLD = 1
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,7 +122,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if _dist_on(world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -134,15 +143,23 @@ def main():
             os.makedirs(os.path.dirname(os.path.abspath(args.json_out)), exist_ok=True)
             with open(args.json_out, "w") as f:
                 f.write(line + "\n")
-    if world > 1:
+    if _dist_on(world):
         dist.barrier()
         dist.destroy_process_group()
     return result
 
 
+_ONE_RANK_RCCL = False
+
+
+def _dist_on(world):
+    """Collectives in play: N > 1, or the one-rank RCCL rehearsal (--rccl-one-rank)."""
+    return world > 1 or _ONE_RANK_RCCL
+
+
 def timed(one_step, steps, warmup, world, dev):
     def sync():
-        if world > 1:
+        if _dist_on(world):
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -154,7 +171,7 @@ def timed(one_step, steps, warmup, world, dev):
         one_step()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if _dist_on(world):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -193,7 +210,7 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
         return (pkg["render_color"], pkg["allmap"]), (dcolor, dallmap)
 
     # gradients are produced directly in the all-reduce bucket whenever the bucket is consumed (N > 1, fused Adam)
-    ba = ba_shard.KeyframeShardedBA(params, render_fn, direct_grads=(world > 1 or args.adam == "fused"), streams=args.streams)
+    ba = ba_shard.KeyframeShardedBA(params, render_fn, direct_grads=(_dist_on(world) or args.adam == "fused"), streams=args.streams)
     kpg = max(1, args.keyframes_per_gpu)
     keyframes = list(range(world * kpg))  # keyframe i goes to rank i % world
     opt = None
@@ -217,7 +234,7 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
 
     # N > 1: chunked/overlapped or whole-bucket all-reduce, whichever is faster on this node (untimed setup, before the warm-up)
     tuned, tune_error = {}, None
-    if world > 1 and kpg == 1 and not args.adam:
+    if _dist_on(world) and kpg == 1 and not args.adam:
         try:
             tuned = ba.autotune(keyframes)
         except Exception as ex:  # noqa: BLE001 -- the N > 1 RCCL path cannot be rehearsed on the one-GPU build box: never let
@@ -229,7 +246,7 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
     frames = args.steps * world * kpg
     ms_per_step = elapsed / args.steps * 1e3
     allreduce_ms = None
-    if world > 1:  # the collective alone, on the same bucket (reported separately)
+    if _dist_on(world):  # the collective alone, on the same bucket (reported separately)
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
@@ -326,10 +343,10 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"synthetic {W}x{H} / {P} Gaussians ({args.workload}; BASELINE.md section 2), {regime} regime, "
                                f"use_sa={use_sa}, {kpg} keyframe{'s' if kpg > 1 else ''} per GPU" + (f" on {args.streams} HIP streams" if kpg > 1 and args.streams > 1 else ""), "num_rendered": R, "num_rendered_reference_rects": R_ref, "visible": visible,
-                   "step": "op forward+backward" + (" + all-reduce of the [P,13] grad bucket" if world > 1 else "")
+                   "step": "op forward+backward" + (" + all-reduce of the [P,13] grad bucket" if _dist_on(world) else "")
                            + (f" + {args.adam} Adam (lr=0)" if args.adam else ""),
                    "parallelism": f"keyframe-sharded x{world}", "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
-                   "allreduce_chunks": ba.overlap_chunks if world > 1 else None,
+                   "allreduce_chunks": ba.overlap_chunks if _dist_on(world) else None,
                    "allreduce_chunks_tuning_ms": {str(k): round(v, 4) for k, v in tuned.items()} or None,
                    "allreduce_tuning_error": tune_error},
         "roofline": roofline, "cpu_baseline": cpu_baseline,
@@ -341,7 +358,7 @@ def slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world):
     fused formulation this package offers (gaus_slam_amd/tracking.py, loss.py, optim.py)."""
     import numpy as np
     from gaus_slam_amd import loss as gl, optim as gs_optim, tracking
-    if world > 1:
+    if _dist_on(world):
         raise SystemExit("the tracking / mapping workloads are single-GPU iterations")
     names = ("means3D", "opacities", "scales", "rotations", "colors")
     g = torch.Generator().manual_seed(0)

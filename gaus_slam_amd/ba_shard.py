@@ -19,6 +19,15 @@ BUCKET_FIELDS = OrderedDict([("means3D", 3), ("opacities", 1), ("scales", 2), ("
 BUCKET_FLOATS = sum(BUCKET_FIELDS.values())  # 13
 
 
+# World sizes below this skip every collective (a one-rank job is the single-GPU path).  tests/test_gpu_multirank.py sets it
+# to 1 to drive the RCCL calls below on the one GPU of a test box -- a one-rank RCCL communicator accepts them all.
+MIN_COLLECTIVE_WORLD = 2
+
+
+def _collective(group=None):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) >= MIN_COLLECTIVE_WORLD
+
+
 class GradBucket:
     """Flat [13*P] fp32 buffer; each field is a contiguous [P,k] view (SoA segments, so packing a gradient is one
     contiguous copy and the collective is one large message: xGMI is per-link bound, fewer/larger is better)."""
@@ -42,7 +51,7 @@ class GradBucket:
                 v.copy_(g.reshape(v.shape))
 
     def all_reduce(self, group=None, average=False):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if _collective(group):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             if average:
                 self.flat.div_(dist.get_world_size(group))
@@ -51,7 +60,7 @@ class GradBucket:
     def reduce_rows(self, g0, g1, group=None):
         """Start the all-reduce(sum) of Gaussians [g0, g1): the five field slices as ONE coalesced, asynchronous collective
         (a single grouped launch under RCCL).  Called while later rows are still being computed; finish with wait()."""
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1) or g1 <= g0:
+        if not _collective(group) or g1 <= g0:
             return
         if dist.get_backend(group) == "nccl" or not self.flat.is_cuda:
             # no `device` argument: the slices are recorded and issued as ONE allreduce_coalesced when the context closes
@@ -69,7 +78,7 @@ class GradBucket:
         for cm in self._pending:
             cm.wait()
         self._pending = []
-        if average and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if average and _collective(group):
             self.flat.div_(dist.get_world_size(group))
         return self.flat
 
@@ -84,13 +93,16 @@ class KeyframeShardedBA:
     render_loss_fn(params, keyframe) -> scalar loss OR (outputs, upstream_grads) pair for torch.autograd.backward.
     """
 
-    def __init__(self, params, render_loss_fn, group=None, average=False, direct_grads=False, streams=1, overlap_chunks=4):
+    def __init__(self, params, render_loss_fn, group=None, average=False, direct_grads=False, streams=1, overlap_chunks=1):
         """direct_grads: let the rasterizer's backward write the parameter gradients straight into the bucket (no pack
         copies).  Safe in every case -- a gradient that did not land in the bucket (the op was not fed the leaf itself,
         e.g. activations in between) is packed by copy as before.
         overlap_chunks: with direct_grads and one keyframe per rank, the per-Gaussian stage of the backward runs in that
         many chunks of Gaussian indices and each chunk's gradients are all-reduced while the next chunk is computed
-        (SURVEY.md section 8(e)); 1 = one all-reduce of the whole bucket after the backward."""
+        (SURVEY.md section 8(e)); 1 (default) = one all-reduce of the whole bucket after the backward.  Every extra chunk
+        costs ~40 us of a step (one more kernel of the per-Gaussian stage, a stream hand-over to and from RCCL's stream, five
+        more collectives) and can hide at most that stage's 26 us, so chunking only pays on a slow interconnect: autotune()
+        decides by measurement."""
         self.direct_grads = direct_grads
         self.overlap_chunks = max(1, int(overlap_chunks))
         self._overlap_ok = False  # set once a chunked reduction has completed
@@ -136,7 +148,7 @@ class KeyframeShardedBA:
         """All-gather of the rank-local per-keyframe parameters after a step (pose quaternion 4 + translation 3 + exposure 2
         = 9 scalars in the reference, scene/Frame.py:84-92): [n] -> [world_size, n], row r = rank r's keyframe."""
         t = local_params.detach().reshape(-1).contiguous()
-        if self.world_size == 1:
+        if not _collective(self.group):
             return t.unsqueeze(0).clone()
         out = torch.empty(self.world_size * t.numel(), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t, group=self.group)
@@ -200,20 +212,24 @@ class KeyframeShardedBA:
                 v.div_(self.world_size)
         return self.bucket.views
 
-    def autotune(self, keyframes, candidates=(1, 2, 4), reps=3):
+    def autotune(self, keyframes, candidates=(1, 2, 4), reps=10, warmup=3, margin=0.02):
         """Pick overlap_chunks by measurement on the machine at hand: one whole-bucket all-reduce after the backward (1) against
         chunked reductions overlapped with the per-Gaussian stage.  Chunking hides at most the length of that stage (26 us at
-        500k Gaussians) and pays one collective latency per extra chunk, so which one wins depends on the interconnect and
-        the bucket size.  Every candidate runs `reps` steps after one untimed step; ranks agree on the choice through a MAX
-        all-reduce of their times.  Returns {candidate: ms per step}; a no-op (returns {}) for world size 1."""
-        if self.world_size == 1 or not self.direct_grads or not self.params["means3D"].is_cuda:
+        500k Gaussians) and pays for every extra chunk: one collective latency on the wire and ~50 us of host work in
+        torch.distributed (scripts/dev/rccl_one_rank_overhead.py: on a one-rank communicator, where the collective itself is
+        free, 2 / 4 chunks cost +43 / +100 us per step and the whole-bucket form nothing) -- so which one wins depends on the
+        interconnect and the bucket size, and a chunked form has to beat the whole-bucket one by `margin` to be chosen.
+        Every candidate runs `reps` timed steps after `warmup` untimed ones; ranks agree on the choice through a MAX
+        all-reduce of their times.  Returns {candidate: ms per step}; a no-op (returns {}) without collectives."""
+        if not _collective(self.group) or not self.direct_grads or not self.params["means3D"].is_cuda:
             return {}
         import time
         dev = self.params["means3D"].device
         times = {}
         for c in candidates:
             self.overlap_chunks = max(1, int(c))
-            self.step(keyframes)
+            for _ in range(max(1, warmup)):
+                self.step(keyframes)
             torch.cuda.synchronize(dev)
             dist.barrier(group=self.group)
             t0 = time.perf_counter()
@@ -223,14 +239,18 @@ class KeyframeShardedBA:
             t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
             times[int(c)] = float(t.item())
-        self.overlap_chunks = min(times, key=lambda k: (times[k], k))  # identical on every rank
+        # identical on every rank (the times are the all-reduced maxima)
+        best = min(times, key=lambda k: (times[k], k))
+        if 1 in times and best != 1 and times[best] > (1.0 - margin) * times[1]:
+            best = 1
+        self.overlap_chunks = best
         return times
 
     def step(self, keyframes):
         """One BA step over a batch of keyframes (len == world_size in the bench; ragged batches allowed: ranks
         without a keyframe contribute zeros).  Returns the reduced bucket views (name -> [P,k])."""
         mine = shard_keyframes(keyframes, self.rank, self.world_size)
-        if self.world_size == 1 and len(mine) == 1:
+        if not _collective(self.group) and len(mine) == 1:
             # degenerate K=1 case == the single-GPU path, bit for bit: no bucket, no copies, no collective
             g = self.local_backward(mine[0], self.bucket.views if self.direct_grads else None)
             return OrderedDict((name, g[name].reshape(v.shape) if g.get(name) is not None else torch.zeros_like(v))
