@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--keyframes-per-gpu", type=int, default=1, help="keyframes each rank renders per step (default 1 = the "
                     "headline metric); rendered one after the other unless --streams 2")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams a rank spreads its keyframes over (ba_shard.KeyframeShardedBA)")
+    ap.add_argument("--tune-allreduce", action="store_true", help="N > 1: time 1 / 2 / 4 all-reduce chunks overlapped with the "
+                    "backward's per-Gaussian stage before the run and use the fastest (default: one whole-bucket all-reduce)")
     ap.add_argument("--rccl-one-rank", action="store_true", help="rehearsal on one GPU: create a ONE-rank RCCL communicator and "
                     "run the N > 1 code path (bucket, chunked all-reduce, autotune, collective timing) through the real library; "
                     "not a performance number")
@@ -232,9 +234,12 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
                 ba.bucket.pack(g)
             opt.step(ba.bucket.flat)
 
-    # N > 1: chunked/overlapped or whole-bucket all-reduce, whichever is faster on this node (untimed setup, before the warm-up)
+    # N > 1: one all-reduce of the whole bucket per step.  --tune-allreduce additionally times the chunked / overlapped forms
+    # in an untimed setup phase and runs with the fastest; off by default because on one rank every extra chunk measured
+    # +40 us against at most 26 us it can hide (profiles/rccl_one_rank_overhead_r02.txt), and the plain dist.all_reduce is
+    # the form least likely to meet a surprise on a node this build never saw.
     tuned, tune_error = {}, None
-    if _dist_on(world) and kpg == 1 and not args.adam:
+    if _dist_on(world) and kpg == 1 and not args.adam and args.tune_allreduce:
         try:
             tuned = ba.autotune(keyframes)
         except Exception as ex:  # noqa: BLE001 -- the N > 1 RCCL path cannot be rehearsed on the one-GPU build box: never let
