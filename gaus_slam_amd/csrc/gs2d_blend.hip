@@ -555,13 +555,35 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
 // the accumulator at the end of the trip (0.338 ms, the latency enters the dependency chain), merging twin rows' totals
 // with v_permlane16/32_swap so that no trip needs the atomic (0.330 ms, +4 spills), and a per-row instead of
 // wave-uniform fallback (no change).
+// min over the six pairs of a ^ b: 0 iff two of the four (wave-uniform) values are equal.  Scalar unit only -- written out
+// because the compiler finishes the plain C++ form with v_mov / v_min3_u32 / v_cmp on the vector unit, the backward's
+// bottleneck.
+__device__ __forceinline__ uint32_t least_pair_xor(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    uint32_t m, t;
+    asm("s_xor_b32 %0, %2, %3\n\t"
+        "s_xor_b32 %1, %2, %4\n\t"
+        "s_min_u32 %0, %0, %1\n\t"
+        "s_xor_b32 %1, %2, %5\n\t"
+        "s_min_u32 %0, %0, %1\n\t"
+        "s_xor_b32 %1, %3, %4\n\t"
+        "s_min_u32 %0, %0, %1\n\t"
+        "s_xor_b32 %1, %3, %5\n\t"
+        "s_min_u32 %0, %0, %1\n\t"
+        "s_xor_b32 %1, %4, %5\n\t"
+        "s_min_u32 %0, %0, %1"
+        : "=&s"(m), "=&s"(t)
+        : "s"(a), "s"(b), "s"(c), "s"(d)
+        : "scc");
+    return m;
+}
 #define GS2D_BWD_ACC_PRE(JJ)                                                                                            \
     const int ai_ = ((JJ) & 63) * NACC + (acc_comp < 0 ? 0 : acc_comp);                                                 \
     const float acc_old_ = wb.acc[ai_];                                                                                 \
     const uint32_t ja_ = __builtin_amdgcn_readlane(JJ, 0), jb_ = __builtin_amdgcn_readlane(JJ, 16),                     \
                    jc_ = __builtin_amdgcn_readlane(JJ, 32), jd_ = __builtin_amdgcn_readlane(JJ, 48);                    \
     /* an exhausted row reads its own end marker (252 + row), so two of those never look like a shared splat */         \
-    const bool clash_ = min(min(min(ja_ ^ jb_, ja_ ^ jc_), min(ja_ ^ jd_, jb_ ^ jc_)), min(jb_ ^ jd_, jc_ ^ jd_)) == 0u;
+    const bool clash_ = least_pair_xor(ja_, jb_, jc_, jd_) == 0u;
 #ifdef GS2D_EXPERIMENT
 #define GS2D_BWD_LDS_ACCUM(JJ, V) if ((V) != 0.f) GS2D_EXP_LDSADD(&wb.acc[((JJ) & 63) * NACC + acc_comp], V);
 #else
