@@ -72,6 +72,7 @@ def latest_profile(stem):
 
 
 def main():
+    global PREWARM_STEPS, _ONE_RANK_RCCL
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -92,6 +93,8 @@ def main():
     ap.add_argument("--keyframes-per-gpu", type=int, default=1, help="keyframes each rank renders per step (default 1 = the "
                     "headline metric); rendered one after the other unless --streams 2")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams a rank spreads its keyframes over (ba_shard.KeyframeShardedBA)")
+    ap.add_argument("--prewarm-steps", type=int, default=PREWARM_STEPS, help="untimed steps before the warm-up that take the GPU "
+                    "out of its idle clocks (0 = none); reported in config.prewarm_steps")
     ap.add_argument("--tune-allreduce", action="store_true", help="N > 1: time 1 / 2 / 4 all-reduce chunks overlapped with the "
                     "backward's per-Gaussian stage before the run and use the fastest (default: one whole-bucket all-reduce)")
     ap.add_argument("--rccl-one-rank", action="store_true", help="rehearsal on one GPU: create a ONE-rank RCCL communicator and "
@@ -108,11 +111,11 @@ def main():
                "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
     if args.rccl_one_rank:
-        global _ONE_RANK_RCCL
         _ONE_RANK_RCCL = True
         from gaus_slam_amd import ba_shard as _bs
         _bs.MIN_COLLECTIVE_WORLD = 1
         os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    PREWARM_STEPS = max(0, args.prewarm_steps)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,12 +162,22 @@ def _dist_on(world):
     return world > 1 or _ONE_RANK_RCCL
 
 
+PREWARM_STEPS = 400
+
+
 def timed(one_step, steps, warmup, world, dev):
     def sync():
         if _dist_on(world):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed, before the W warm-up steps: bring the GPU out of its idle power state.  A bench process that has just
+    # finished its setup times its first ~30 ms at ramping clocks (scripts/dev/fill_cost.py: the same loop, 0.554 ms per
+    # step when it starts 10 steps after idle, 0.539 ms once the card has been busy for a few hundred ms); the metric is
+    # the steady-state rate.  A fixed count, so that every rank issues the same collectives.
+    for _ in range(PREWARM_STEPS):
+        one_step()
+    sync()
     for _ in range(warmup):
         one_step()
     sync()
@@ -350,7 +363,7 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
                                f"use_sa={use_sa}, {kpg} keyframe{'s' if kpg > 1 else ''} per GPU" + (f" on {args.streams} HIP streams" if kpg > 1 and args.streams > 1 else ""), "num_rendered": R, "num_rendered_reference_rects": R_ref, "visible": visible,
                    "step": "op forward+backward" + (" + all-reduce of the [P,13] grad bucket" if _dist_on(world) else "")
                            + (f" + {args.adam} Adam (lr=0)" if args.adam else ""),
-                   "parallelism": f"keyframe-sharded x{world}", "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
+                   "parallelism": f"keyframe-sharded x{world}", "prewarm_steps": PREWARM_STEPS, "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
                    "allreduce_chunks": ba.overlap_chunks if _dist_on(world) else None,
                    "allreduce_chunks_tuning_ms": {str(k): round(v, 4) for k, v in tuned.items()} or None,
                    "allreduce_tuning_error": tune_error},
@@ -412,7 +425,7 @@ def slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world):
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {W}x{H} / {P} Gaussians, {args.workload} iteration (BASELINE.json configs[2] loop shape), "
-                                   f"use_sa={use_sa}", "step": step_desc, "parallelism": "single GPU"},
+                                   f"use_sa={use_sa}", "step": step_desc, "parallelism": "single GPU", "prewarm_steps": PREWARM_STEPS},
             "roofline": None, "cpu_baseline": None}
 
 
