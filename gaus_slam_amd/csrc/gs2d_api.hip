@@ -372,7 +372,7 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         if (nulls != 0 && (nulls != 6 || pose_Rt == nullptr || shs != nullptr))
             return fail_msg("per-Gaussian gradient outputs may only be omitted all together, with a pose and without SH");
     }
-    (void)colors_precomp; (void)transMat_precomp; (void)scale_modifier;
+    (void)colors_precomp; (void)transMat_precomp;
     hipStream_t s = (hipStream_t)stream;
     // The pose gradient is accumulated by the preprocess stage(s) and cleared once, by the call that runs the blend stage:
     // inside blend_bwd_kernel when that kernel runs (one launch less on the tracking loop's critical path), else by a memset.
@@ -435,7 +435,8 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         g_timer.begin(ST_PREPROCESS_BWD, s);
         gs2d::launch_preprocess_bwd(g_begin, g_end, D, M, means3D, rec, radii, shs, clamped, scales, rotations, cam, grad_rec,
                                     dL_dtransMat, dL_dnormal, dL_dcolor, dL_dopacity, dL_dsh, dL_dmean2D, dL_dmean3D,
-                                    dL_dscale, dL_drot, pose_Rt, pose_quat, pose_Rt ? dL_dpose : nullptr, s);
+                                    dL_dscale, dL_drot, pose_Rt, pose_quat, pose_Rt ? dL_dpose : nullptr,
+                                    /*need_record=*/scale_modifier != 1.0f, s);
         g_timer.end(ST_PREPROCESS_BWD, s);
         GS2D_STAGE("preprocess_bwd");
     }

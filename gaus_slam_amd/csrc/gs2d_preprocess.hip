@@ -440,9 +440,13 @@ preprocess_bwd_one(int idx, int P, int D, int M, const float* __restrict__ means
     float Pm[4][3];
     Mat3 R;
     float sx = 0.f, sy = 0.f, w = 0.f, x = 0.f, y = 0.f, z = 0.f, qsign = 1.f;
-    const float4* rp = rec + (size_t)idx * GS2D_REC_F4;
-    const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+    // rec == nullptr (launch_preprocess_bwd): Tw.z, the one word of the record the usual path needs, is recomputed below bit
+    // for bit, so the 80-byte-strided record reads (a whole line per Gaussian for four useful bytes) are not issued
+    float4 q2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rec != nullptr) q2 = rec[(size_t)idx * GS2D_REC_F4 + 2];
     if (precomp) {
+        const float4* rp = rec + (size_t)idx * GS2D_REC_F4;
+        const float4 q0 = rp[0], q1 = rp[1];
         T[0] = q0.x; T[1] = q0.y; T[2] = q0.z; T[3] = q1.x; T[4] = q1.y; T[5] = q1.z; T[6] = q2.x; T[7] = q2.y; T[8] = q2.z;
     } else {
         float4 q = reinterpret_cast<const float4*>(rotations)[idx];
@@ -548,7 +552,7 @@ preprocess_bwd_one(int idx, int P, int D, int M, const float* __restrict__ means
         for (int i = 0; i < 9; i++) dL_dtransMat[9 * (size_t)idx + i] = dTout[i];
     }
     // densification hack, backward.cu:660-663 (double arithmetic as written in the reference)
-    const float depth = q2.z;
+    const float depth = rec != nullptr ? q2.z : T[8];
     dL_dmean2D[3 * idx + 0] = (float)((double)(dTout[2] * depth) * 0.5 * (double)(float)cam.W);
     dL_dmean2D[3 * idx + 1] = (float)((double)(dTout[5] * depth) * 0.5 * (double)(float)cam.H);
     dL_dmean2D[3 * idx + 2] = 0.f;
@@ -624,9 +628,13 @@ void launch_preprocess_bwd(int first, int P, int D, int M, const float* means3D,
                            const CamParams& cam, const float* grad_rec, float* dL_dtransMat, float* dL_dnormal,
                            float* dL_dcolor, float* dL_dopacity, float* dL_dsh, float* dL_dmean2D,
                            float* dL_dmean3D, float* dL_dscale, float* dL_drot, const float* pose_Rt, const float* pose_q,
-                           float* dL_dpose, hipStream_t s)
+                           float* dL_dpose, int need_record, hipStream_t s)
 {
     if (P <= first) return;
+    // The per-Gaussian code needs the forward's Tw.z (record word 10).  With scales / rotations and scale_modifier == 1 it
+    // recomputes the whole transform from the same inputs with the same code (-ffp-contract=off: same IEEE operations), Tw.z
+    // included (it does not depend on the image size the backward re-derives), so the records stay unread: -25 % traffic.
+    if (scales != nullptr && !need_record) rec = nullptr;
     int grid = (P - first + 255) / 256;
     // every workgroup ends with 12 atomics on the same pose-gradient words (1954 workgroups at 500k Gaussians: +14 us);
     // two Gaussians per thread halve that without starving the memory system of waves

@@ -89,6 +89,26 @@ def test_debug_flag_and_scale_modifier(oracle):
     assert np.abs(h["allmap"] - o["allmap"])[:, stable].max() <= IMG_TOL
 
 
+def test_backward_with_a_scale_modifier(oracle):
+    """scale_modifier != 1: the backward ignores the modifier when it rebuilds the transform (backward.cu:504) but its
+    means2D output uses the FORWARD's Tw.z (backward.cu:660-663) -- the one case in which the library's preprocess backward
+    still reads the geometry records instead of recomputing that word."""
+    W, H = 128, 96
+    sc = util.make_scene(800, W, H, seed=7, regime="mapping")
+    o = util.oracle_forward(oracle, sc, scale_modifier=1.7)
+    h = util.hip_forward(sc, scale_modifier=1.7)
+    np.testing.assert_array_equal(h["point_list"], o["point_list"])
+    stable = (o["stability"] > KNIFE).reshape(H, W)
+    dc, da = util.make_upstream_grads(W, H, channels=(0, 1, 5, 6))
+    dc = (dc * W * H).numpy(); da = (da * W * H).numpy()
+    dc[:, ~stable] = 0; da[:, ~stable] = 0
+    go = oracle.backward(o, dc, da)
+    gh = util.hip_backward(h, dc, da)
+    for k in ["dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"]:
+        assert util.grad_err(gh[k], go[k].reshape(gh[k].shape)) <= 1e-4, k
+    assert np.abs(gh["dL_dmeans2D"]).max() > 0
+
+
 def test_culling_stress_extreme_splats(oracle):
     """Grazing, huge, tiny, near-plane and behind-the-eye-crossing surfels: the quadrant cull must never drop a
     contributing pair (bit-exact n_contrib / images vs the oracle, which has no culling)."""
