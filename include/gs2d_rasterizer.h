@@ -83,7 +83,10 @@ int gs2d_forward(
     int use_sa, int debug, void* stream);
 
 /* Every element of every dL_* output is written (zeros for Gaussians culled by the forward), so the caller may
- * pass uninitialised memory; the reference relies on torch::zeros instead (rasterize_points.cu:192-200). */
+ * pass uninitialised memory; the reference relies on torch::zeros instead (rasterize_points.cu:192-200).
+ * scale_modifier: the value the forward was called with, as the reference's autograd function passes it
+ * (RAST/gaus_2dgs_rasterization/__init__.py:67 and :116, the same raster_settings).  The rebuilt transform ignores it (backward.cu:504); the library uses it
+ * to know whether the forward's Tw.z can be recomputed (== 1) or has to be read from the geometry chunk (!= 1). */
 int gs2d_backward(
     int P, int D, int M, int R,
     const float* background,
