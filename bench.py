@@ -162,7 +162,7 @@ def _dist_on(world):
     return world > 1 or _ONE_RANK_RCCL
 
 
-PREWARM_STEPS = 400
+PREWARM_STEPS = 1000
 
 
 def timed(one_step, steps, warmup, world, dev):
