@@ -196,3 +196,41 @@ def test_second_backward_on_the_same_forward_is_clean():
         assert np.abs(g1[k]).max() > 0
         assert util.grad_err(g2[k], g1[k]) <= 1e-5, k
         assert util.grad_err(g3[k], 2 * g1[k]) <= 1e-5, k
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_default_and_deterministic_backward_agree_on_random_scenes(case):
+    """The default backward (plain-store / LDS-atomic accumulate per trip, global float atomics per batch) against the
+    atomic-free deterministic one on random image sizes (ragged edge tiles), scene sizes, splat scales, regimes, both
+    distortion modes, with and without gradients on the normal channels: equal up to summation order."""
+    from gaus_slam_amd import rasterizer, render as gs_render
+    from gaus_slam_amd.scene_synth import make_scene, make_upstream_grads
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(1000 + case)
+    W = int(rng.integers(3, 40)) * 16 - int(rng.integers(0, 16))
+    H = int(rng.integers(3, 30)) * 16 - int(rng.integers(0, 16))
+    P = int(rng.choice([50, 700, 5000, 40000]))
+    sc = make_scene(P, W, H, seed=200 + case, regime=["mapping", "tracking"][case % 2], scale_lo=0.3,
+                    scale_hi=float(rng.choice([4.0, 12.0, 40.0])))
+    chans = (0, 1, 5, 6) if case % 3 else (0, 1, 2, 3, 4, 5, 6)
+    dc, da = make_upstream_grads(W, H, seed=case, channels=chans)
+    dc, da = (dc * W * H).to(dev), (da * W * H).to(dev)
+    st = gs_render.settings_from_camera(sc["cam"], dev, use_sa=bool(case % 4))
+    names = ("means3D", "opacities", "scales", "rotations", "colors")
+    res = []
+    try:
+        for det in (False, True):
+            rasterizer.set_deterministic(det)
+            p = {k: sc[k].to(dev).requires_grad_(True) for k in names}
+            m2 = torch.zeros_like(p["means3D"], requires_grad=True)
+            pkg = gs_render.render(st, p["means3D"], m2, p["opacities"], colors_precomp=p["colors"], scales=p["scales"],
+                                   rotations=p["rotations"])
+            torch.autograd.backward([pkg["render_color"], pkg["allmap"]], [dc, da])
+            res.append([p[k].grad.double().cpu() for k in names] + [m2.grad.double().cpu()])
+    finally:
+        rasterizer.set_deterministic(False)
+    for name, a, b in zip(names + ("means2D",), *res):
+        assert torch.isfinite(a).all() and torch.isfinite(b).all(), name
+        scale = float(b.abs().max())
+        if scale > 0:
+            assert float((a - b).abs().max()) <= 1e-5 * scale, (name, W, H, P)
