@@ -93,8 +93,8 @@ def main():
     ap.add_argument("--keyframes-per-gpu", type=int, default=1, help="keyframes each rank renders per step (default 1 = the "
                     "headline metric); rendered one after the other unless --streams 2")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams a rank spreads its keyframes over (ba_shard.KeyframeShardedBA)")
-    ap.add_argument("--prewarm-steps", type=int, default=PREWARM_STEPS, help="untimed steps before the warm-up that take the GPU "
-                    "out of its idle clocks (0 = none); reported in config.prewarm_steps")
+    ap.add_argument("--prewarm-steps", type=int, default=PREWARM_STEPS, help="upper bound on the untimed steps before the warm-up that take "
+                    "the GPU out of its idle clocks (about 1.6 s worth are run; 0 = none); the count is reported in config.prewarm_steps")
     ap.add_argument("--tune-allreduce", action="store_true", help="N > 1: time 1 / 2 / 4 all-reduce chunks overlapped with the "
                     "backward's per-Gaussian stage before the run and use the fastest (default: one whole-bucket all-reduce)")
     ap.add_argument("--rccl-one-rank", action="store_true", help="rehearsal on one GPU: create a ONE-rank RCCL communicator and "
@@ -162,7 +162,9 @@ def _dist_on(world):
     return world > 1 or _ONE_RANK_RCCL
 
 
-PREWARM_STEPS = 1000
+PREWARM_STEPS = 3000    # upper bound
+PREWARM_SECONDS = 1.6   # target duration
+PREWARM_DONE = 0        # steps actually run (reported as config.prewarm_steps)
 
 
 def timed(one_step, steps, warmup, world, dev):
@@ -174,10 +176,27 @@ def timed(one_step, steps, warmup, world, dev):
     # Untimed, before the W warm-up steps: bring the GPU out of its idle power state.  A bench process that has just
     # finished its setup times its first ~30 ms at ramping clocks (scripts/dev/fill_cost.py: the same loop, 0.554 ms per
     # step when it starts 10 steps after idle, 0.539 ms once the card has been busy for a few hundred ms); the metric is
-    # the steady-state rate.  A fixed count, so that every rank issues the same collectives.
-    for _ in range(PREWARM_STEPS):
-        one_step()
-    sync()
+    # the steady-state rate.  About PREWARM_SECONDS of steps, at most PREWARM_STEPS; the count is derived from the slowest
+    # rank's time for steps 11-60, so that every rank issues the same collectives.
+    global PREWARM_DONE
+    PREWARM_DONE = 0
+    if PREWARM_STEPS > 0:
+        n0 = min(60, PREWARM_STEPS)
+        for _ in range(min(10, n0)):  # first launches: code objects load, the allocator grows
+            one_step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n0 - min(10, n0)):
+            one_step()
+        sync()
+        dt = torch.tensor([(time.perf_counter() - t0) / max(1, n0 - 10)], dtype=torch.float64, device=dev)
+        if _dist_on(world):
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        n1 = int(max(0, min(PREWARM_STEPS - n0, PREWARM_SECONDS / max(float(dt.item()), 1e-6) - n0)))
+        for _ in range(n1):
+            one_step()
+        sync()
+        PREWARM_DONE = n0 + n1
     for _ in range(warmup):
         one_step()
     sync()
@@ -363,7 +382,7 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
                                f"use_sa={use_sa}, {kpg} keyframe{'s' if kpg > 1 else ''} per GPU" + (f" on {args.streams} HIP streams" if kpg > 1 and args.streams > 1 else ""), "num_rendered": R, "num_rendered_reference_rects": R_ref, "visible": visible,
                    "step": "op forward+backward" + (" + all-reduce of the [P,13] grad bucket" if _dist_on(world) else "")
                            + (f" + {args.adam} Adam (lr=0)" if args.adam else ""),
-                   "parallelism": f"keyframe-sharded x{world}", "prewarm_steps": PREWARM_STEPS, "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
+                   "parallelism": f"keyframe-sharded x{world}", "prewarm_steps": PREWARM_DONE, "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
                    "allreduce_chunks": ba.overlap_chunks if _dist_on(world) else None,
                    "allreduce_chunks_tuning_ms": {str(k): round(v, 4) for k, v in tuned.items()} or None,
                    "allreduce_tuning_error": tune_error},
@@ -425,7 +444,7 @@ def slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world):
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {W}x{H} / {P} Gaussians, {args.workload} iteration (BASELINE.json configs[2] loop shape), "
-                                   f"use_sa={use_sa}", "step": step_desc, "parallelism": "single GPU", "prewarm_steps": PREWARM_STEPS},
+                                   f"use_sa={use_sa}", "step": step_desc, "parallelism": "single GPU", "prewarm_steps": PREWARM_DONE},
             "roofline": None, "cpu_baseline": None}
 
 
