@@ -116,6 +116,11 @@ def main():
         _bs.MIN_COLLECTIVE_WORLD = 1
         os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
     PREWARM_STEPS = max(0, args.prewarm_steps)
+    # stdout carries exactly ONE line, the JSON: whatever libraries print on file descriptor 1 while the job runs (RCCL writes
+    # a five-line version banner there when a communicator is created) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,7 +148,8 @@ def main():
         result = op_workload(args, dev, P, W, H, regime, use_sa, rank, world)
     if rank == 0 and result is not None:
         line = json.dumps(result)
-        print(line, flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (line + "\n").encode())
         if args.json_out:
             os.makedirs(os.path.dirname(os.path.abspath(args.json_out)), exist_ok=True)
             with open(args.json_out, "w") as f:
