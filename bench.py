@@ -243,7 +243,9 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
     last = {}
 
     def render_fn(p, _kf):
-        means2D = torch.zeros_like(p["means3D"], requires_grad=True)
+        # gradient carrier only: neither the reference's extension (its Python wrapper does not even pass it down,
+        # RAST/gaus_2dgs_rasterization/__init__.py:59-80) nor this library reads its values, so no fill kernel is spent on it
+        means2D = torch.empty_like(p["means3D"]).requires_grad_(True)
         pkg = gs_render.render(settings, p["means3D"], means2D, p["opacities"], colors_precomp=p["colors"],
                                scales=p["scales"], rotations=p["rotations"])
         last["radius"] = pkg["radius"]
@@ -431,7 +433,7 @@ def slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world):
         fopt = gs_optim.FusedGaussianAdam(soa, {})
 
         def rasterize(q):
-            m2 = torch.zeros_like(q["means3D"], requires_grad=True)
+            m2 = torch.empty_like(q["means3D"]).requires_grad_(True)  # gradient carrier, values never read
             return gs_render.render(settings, q["means3D"], m2, q["opacities"], colors_precomp=q["colors"], scales=q["scales"],
                                     rotations=q["rotations"])
 

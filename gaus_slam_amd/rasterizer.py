@@ -332,6 +332,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
+        # autograd would otherwise hand the backward a freshly zero-filled [P] int tensor as the "gradient" of radii on every
+        # call (a fill kernel on the stream between the two blend kernels); gradients that really are absent become zeros below
+        ctx.set_materialize_grads(False)
+        ctx.image_shape = (color.shape, depth.shape)
         return color, radii, depth
 
     @staticmethod
@@ -339,6 +343,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
+        if grad_out_color is None:  # only the other image fed the loss
+            grad_out_color = torch.zeros(ctx.image_shape[0], dtype=torch.float32, device=means3D.device)
+        if grad_depth is None:
+            grad_depth = torch.zeros(ctx.image_shape[1], dtype=torch.float32, device=means3D.device)
         sink, chunk_rows, on_chunk = _take_sink()  # one backward per sink; a second one raises
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = rasterize_gaussians_backward(

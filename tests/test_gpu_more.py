@@ -427,3 +427,36 @@ def test_two_keyframes_per_rank_on_two_streams_match_sequential(oracle):
     for k in names:
         assert util.grad_err(res[1][k].cpu().numpy(), res[0][k].cpu().numpy()) < 1e-5, k
         assert float(res[0][k].abs().max()) > 0
+
+
+def test_backward_through_one_output_only():
+    """A loss that uses only one of the two images: autograd hands the operator's backward no gradient for the other one
+    (the function does not let it materialise zeros, which would also cost a [P] fill for `radii` on every call)."""
+    from gaus_slam_amd import render as gs_render
+    dev = torch.device("cuda", 0)
+    W, H = 112, 80
+    sc = util.make_scene(900, W, H, seed=9, regime="mapping")
+    st = gs_render.settings_from_camera(sc["cam"], dev, use_sa=True)
+    names = ("means3D", "opacities", "scales", "rotations", "colors")
+
+    def grads(which):
+        p = {k: sc[k].to(dev).requires_grad_(True) for k in names}
+        m2 = torch.empty_like(p["means3D"]).requires_grad_(True)
+        pkg = gs_render.render(st, p["means3D"], m2, p["opacities"], colors_precomp=p["colors"], scales=p["scales"],
+                               rotations=p["rotations"])
+        wc = torch.linspace(0.5, 1.5, 3 * H * W, device=dev).reshape(3, H, W)
+        wa = torch.linspace(-1.0, 1.0, 7 * H * W, device=dev).reshape(7, H, W)
+        if which == "color":
+            (pkg["render_color"] * wc).sum().backward()
+        elif which == "allmap":
+            (pkg["allmap"] * wa).sum().backward()
+        else:
+            torch.autograd.backward([pkg["render_color"], pkg["allmap"]],
+                                    [wc if which == "color+0" else torch.zeros_like(wc),
+                                     torch.zeros_like(wa) if which == "color+0" else wa])
+        return [p[k].grad.double().cpu() for k in names] + [m2.grad.double().cpu()]
+
+    for one, both in (("color", "color+0"), ("allmap", "0+allmap")):
+        for a, b in zip(grads(one), grads(both)):
+            scale = float(b.abs().max())  # 0 for the colours under the allmap-only loss
+            assert float((a - b).abs().max()) <= 1e-5 * scale
