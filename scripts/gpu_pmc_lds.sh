@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 TAG=${1:-lds}
 mkdir -p gpurun_out/prof_$TAG
 export TMPDIR=/tmp
-(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG/lds -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG/lds.log 2>&1) || true
+(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG/lds -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --prewarm-steps 20 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG/lds.log 2>&1) || true
 python3 - <<PY
 import csv, glob, collections
 acc=collections.defaultdict(lambda: collections.defaultdict(list))

@@ -10,13 +10,13 @@ export TMPDIR=/tmp
 if [ "$PART" = "1" ]; then
   timeout -k 10 400 python bench.py --json-out $OUT/bench_final.json > $OUT/bench_final.log 2>&1 || true
   echo "bench done"; tail -c 400 $OUT/bench_final.log
-  (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/trace.log 2>&1) || true
+  (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --prewarm-steps 100 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/trace.log 2>&1) || true
   echo "trace done"
-  (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/pmc_fetch.log 2>&1) || true
-  (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/pmc_write.log 2>&1) || true
+  (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --prewarm-steps 20 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/pmc_fetch.log 2>&1) || true
+  (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --prewarm-steps 20 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/pmc_write.log 2>&1) || true
   echo "traffic done"
-  (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $GRAFT_REPO_ROOT/$OUT/sq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/sq.log 2>&1) || true
-  (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --output-format csv -d $GRAFT_REPO_ROOT/$OUT/sq2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/sq2.log 2>&1) || true
+  (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $GRAFT_REPO_ROOT/$OUT/sq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --prewarm-steps 20 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/sq.log 2>&1) || true
+  (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --output-format csv -d $GRAFT_REPO_ROOT/$OUT/sq2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --prewarm-steps 20 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/sq2.log 2>&1) || true
   echo "sq done"
   python3 scripts/summarize_profile.py $OUT > $OUT/summary.txt 2>&1 || true
   python3 scripts/make_pmc_json.py $OUT > $OUT/make_pmc.log 2>&1 || true
