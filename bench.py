@@ -417,11 +417,12 @@ def slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world):
         # lr = 0: the pose (and so the workload) stays fixed, the update runs; fused=True: one kernel instead of torch's
         # seven foreach launches for this single 4x4 tensor (33 us of a 0.66-ms iteration)
         opt = torch.optim.Adam([w2c], lr=0.0, fused=True)
+        one = torch.ones((), dtype=torch.float32, device=dev)  # seed of loss.backward(): not re-filled in every iteration
 
         def one_step():
             opt.zero_grad(set_to_none=True)
             pkg = tracking.render_tracking(settings, w2c, p["means3D"], p["opacities"], p["colors"], p["scales"], p["rotations"])
-            gl.tracking_loss(pkg["render_color"], pkg["allmap"], gt_color, gt_depth, 0.5, 1.0).backward()
+            gl.tracking_loss(pkg["render_color"], pkg["allmap"], gt_color, gt_depth, 0.5, 1.0).backward(one)
             opt.step()
         step_desc = "pose transform fused into the preprocess + render + fused tracking loss + pose-only backward + Adam on the pose"
         metric = f"tracking iterations/sec @ {W}x{H}, {P // 1000}k Gaussians"

@@ -113,6 +113,7 @@ class KeyframeShardedBA:
         # pair on two streams vs 1.25 ms sequentially, profiles/bench_r02_kpg2*.json).
         self.n_streams = max(1, int(streams))
         self._streams = None
+        self._ones = {}
         self.params = params
         self.fn = render_loss_fn
         self.group = group
@@ -141,7 +142,15 @@ class KeyframeShardedBA:
                 outs, ups = res
                 torch.autograd.backward(list(outs), list(ups))
             else:
-                res.backward()
+                # the seed gradient of a scalar loss: one cached 1.0 per (device, dtype) instead of autograd's ones_like fill
+                # on the stream in every step
+                key = (res.device, res.dtype)
+                one = self._ones.get(key)
+                if one is None or res.dim() != 0:
+                    one = torch.ones_like(res)
+                    if res.dim() == 0:
+                        self._ones[key] = one
+                res.backward(one)
         return {k: p.grad for k, p in self.params.items()}
 
     def gather_frame_params(self, local_params):

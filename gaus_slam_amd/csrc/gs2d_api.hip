@@ -364,7 +364,10 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
                          float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot, int use_sa,
                          int debug, const float* pose_Rt, const float* pose_quat, float* dL_dpose, void* stream)
 {
-    if ((stages & ~3) != 0 || stages == 0) return fail_msg("stages must be a combination of GS2D_BWD_BLEND (1) and GS2D_BWD_PREPROCESS (2)");
+    if ((stages & ~7) != 0 || (stages & 3) == 0)
+        return fail_msg("stages must be a combination of GS2D_BWD_BLEND (1) and GS2D_BWD_PREPROCESS (2), optionally with GS2D_BWD_POSE_4X4 (4)");
+    if ((stages & GS2D_BWD_POSE_4X4) != 0 && (stages & 3) != 3)
+        return fail_msg("GS2D_BWD_POSE_4X4 needs both stages in one call");
     if ((pose_Rt == nullptr) != (pose_quat == nullptr)) return fail_msg("pose_Rt and pose_quat must be given together");
     if (pose_Rt != nullptr && dL_dpose == nullptr) return fail_msg("dL_dpose is required with a pose");
     if ((stages & 2) != 0) {   // pose-only call: all six per-Gaussian outputs NULL (needs a pose and no SH gradient), otherwise none of them
@@ -376,8 +379,9 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
     hipStream_t s = (hipStream_t)stream;
     // The pose gradient is accumulated by the preprocess stage(s) and cleared once, by the call that runs the blend stage:
     // inside blend_bwd_kernel when that kernel runs (one launch less on the tracking loop's critical path), else by a memset.
+    const int pose_floats = (stages & GS2D_BWD_POSE_4X4) != 0 ? 16 : 12;
     if (dL_dpose != nullptr && (stages & 1) != 0 && (P <= 0 || R <= 0 || g_deterministic.load() != 0))
-        GS2D_CHECK(hipMemsetAsync(dL_dpose, 0, sizeof(float) * 12, s), "memset dL_dpose");
+        GS2D_CHECK(hipMemsetAsync(dL_dpose, 0, sizeof(float) * pose_floats, s), "memset dL_dpose");
     if (P <= 0) return 0;
     if (g_begin < 0 || g_end > P || g_begin > g_end) return fail_msg("bad Gaussian range");
     if (!geom_buffer || !img_buffer || (R > 0 && !binning_buffer)) return fail_msg("missing forward state");
@@ -399,7 +403,7 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         if (R > 0) {
             g_timer.begin(ST_BLEND_BWD, s);
             gs2d::launch_blend_bwd(width, height, ranges, point_list, rec, background, pix_state, hits, dL_dpix, dL_depths,
-                                   grad_rec, use_sa, nullptr, dL_dpose, s);
+                                   grad_rec, use_sa, nullptr, dL_dpose, pose_floats, s);
             g_timer.end(ST_BLEND_BWD, s);
             GS2D_STAGE("blend_bwd");
         }
@@ -413,7 +417,7 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         if (R > 0) {
             GS2D_CHECK(hipMemsetAsync(det_slots, 0, sizeof(float) * GS2D_GRAD_FLOATS * 4 * (size_t)R, s), "memset det_slots");
             gs2d::launch_blend_bwd(width, height, ranges, point_list, rec, background, pix_state, hits, dL_dpix, dL_depths,
-                                   grad_rec, use_sa, det_slots, nullptr, s);
+                                   grad_rec, use_sa, det_slots, nullptr, 0, s);
         }
         gs2d::launch_det_reduce(P, R, width, height, ranges, point_list, (const ushort4*)(geom_buffer + GL.rect),
                                 (const uint32_t*)(geom_buffer + GL.tiles_touched),

@@ -610,9 +610,9 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                  const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ pix_state,
                  size_t plane, const uint8_t* __restrict__ hits, const float* __restrict__ dL_dpix,
                  const float* __restrict__ dL_dothers, float* __restrict__ grad_rec, float* __restrict__ det_slots,
-                 float* __restrict__ clear12)
+                 float* __restrict__ clear12, int clear_n)
 {
-    if (clear12 != nullptr && blockIdx.x == 0 && threadIdx.x < 12) clear12[threadIdx.x] = 0.f;
+    if (clear12 != nullptr && blockIdx.x == 0 && (int)threadIdx.x < clear_n) clear12[threadIdx.x] = 0.f;
     constexpr int NACC = DET ? GS2D_ACC_DET : GS2D_ACC;
     typedef BwdBatchT<NACC> BwdBatch;
     __shared__ BwdBatch batches[4];
@@ -1004,14 +1004,14 @@ void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_l
 
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
                       const float* bg, const float* pix_state, const uint8_t* hits, const float* dL_dpix,
-                      const float* dL_dothers, float* grad_rec, int use_sa, float* det_slots, float* clear12, hipStream_t s)
+                      const float* dL_dothers, float* grad_rec, int use_sa, float* det_slots, float* clear12, int clear_n, hipStream_t s)
 {
     const int gx = (W + GS2D_TILE - 1) / GS2D_TILE, gy = (H + GS2D_TILE - 1) / GS2D_TILE;
     const size_t plane = (size_t)gx * gy * GS2D_TILE_PIX;
     const int grid = GS2D_XCDS * ((gx * gy + GS2D_XCDS - 1) / GS2D_XCDS);
 #define GS2D_LAUNCH_BWD(SA, DET)                                                                                              \
     hipLaunchKernelGGL((blend_bwd_kernel<SA, DET>), dim3(grid), dim3(256), 0, s, W, H, gx, gx * gy, ranges, point_list, rec, bg, \
-                       pix_state, plane, hits, dL_dpix, dL_dothers, grad_rec, det_slots, clear12)
+                       pix_state, plane, hits, dL_dpix, dL_dothers, grad_rec, det_slots, clear12, clear_n)
     if (det_slots) { if (use_sa) GS2D_LAUNCH_BWD(true, true); else GS2D_LAUNCH_BWD(false, true); }
     else { if (use_sa) GS2D_LAUNCH_BWD(true, false); else GS2D_LAUNCH_BWD(false, false); }
 #undef GS2D_LAUNCH_BWD

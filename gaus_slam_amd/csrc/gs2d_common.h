@@ -219,7 +219,7 @@ void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_l
 // (GS2D_GRAD_FLOATS floats each, R * 4 of them, zero-initialised by the caller) that launch_det_reduce then sums
 void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
                       const float* bg, const float* pix_state, const uint8_t* hits, const float* dL_dpix,
-                      const float* dL_dothers, float* grad_rec, int use_sa, float* det_slots, float* clear12, hipStream_t s);
+                      const float* dL_dothers, float* grad_rec, int use_sa, float* det_slots, float* clear12, int clear_n, hipStream_t s);
 // deterministic mode: inv[unsorted instance] = sorted position, then grad_rec[g] = sum of g's slots in a fixed order
 void launch_det_reduce(int P, int R, int W, int H, const uint2* ranges, const uint32_t* point_list, const ushort4* rect,
                        const uint32_t* tiles_touched, const uint32_t* point_offsets, const uint8_t* hits,

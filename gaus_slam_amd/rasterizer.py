@@ -153,7 +153,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     of into fresh tensors.
     lean (used by the autograd node): skip the outputs nobody can observe there -- the internal dL_dnormal and, when no
     cov3D_precomp was given, dL_dtransMat (returned as None): 48 B per Gaussian less to write.
-    pose_only_out (tracking): a zeroed float32 tensor whose first 12 elements receive dL/d[R|t]; no per-Gaussian gradient
+    pose_only_out (tracking): a float32 [4,4] tensor (uninitialised is fine: rows 0-2 receive dL/d[R|t], row 3 zeros -- a
+    zero-filled tensor when P == 0); no per-Gaussian gradient
     is computed or allocated and only that tensor is returned.
     chunk_rows / on_chunk (keyframe-sharded BA): run the per-Gaussian stage in chunks of `chunk_rows` Gaussians
     (gs2d_backward_staged) and call on_chunk(g_begin, g_end) after each chunk has been enqueued -- the caller starts that
@@ -176,14 +177,17 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                        dL_dout_color, dL_dout_others, pose_Rt, pose_quat)]
             bg_, m3_, col_, sc_, rot_, vm_, pm_, cp_, dc_, do_, prt_, pq_ = keep
             with _on_device(dev):
-                rc = L.gs2d_backward_posed(
-                    P, int(degree), 0, int(R), _ptr(bg_), W, H, _ptr(m3_), None, _ptr(col_), _ptr(sc_), float(scale_modifier),
+                # stages 1|2|4 (GS2D_BWD_POSE_4X4): all sixteen floats of pose_only_out are written
+                rc = L.gs2d_backward_staged(
+                    7, 0, P, P, int(degree), 0, int(R), _ptr(bg_), W, H, _ptr(m3_), None, _ptr(col_), _ptr(sc_), float(scale_modifier),
                     _ptr(rot_), None, _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy),
                     radii.contiguous().data_ptr(), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), dc_.data_ptr(),
                     do_.data_ptr(), None, None, None, None, None, None, None, None, None, int(bool(use_sa)), int(bool(debug)),
                     _ptr(prt_), _ptr(pq_), pose_only_out.data_ptr(), _stream_ptr(dev))
             if rc < 0:
                 raise RuntimeError(_lib.last_error())
+        else:
+            pose_only_out.zero_()
         return pose_only_out
     # the backward kernels write every element (zeros for culled Gaussians): no torch.zeros fills needed
     z = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)

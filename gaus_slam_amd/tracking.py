@@ -60,6 +60,8 @@ class _RasterizeTracking(torch.autograd.Function):
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, radii, geom, binning, img, pose_Rt, pose_q)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)  # no zero-filled [P] "gradient" of radii per call (rasterizer._RasterizeGaussians)
+        ctx.image_shape = (color.shape, allmap.shape)
         return color, radii, allmap
 
     @staticmethod
@@ -67,10 +69,15 @@ class _RasterizeTracking(torch.autograd.Function):
         rs = ctx.rs
         colors_precomp, means3D, scales, rotations, radii, geom, binning, img, pose_Rt, pose_q = ctx.saved_tensors
         e = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        if grad_color is None:
+            grad_color = torch.zeros(ctx.image_shape[0], dtype=torch.float32, device=means3D.device)
+        if grad_allmap is None:
+            grad_allmap = torch.zeros(ctx.image_shape[1], dtype=torch.float32, device=means3D.device)
         if not any(ctx.needs_input_grad[1:6]):
             # the reference's tracking renderer detaches every Gaussian parameter (render/__init__.py:31-36): only the
-            # pose gradient is wanted; it is accumulated straight into the first three rows of the [4,4] result
-            g_w2c = torch.zeros((4, 4), dtype=torch.float32, device=means3D.device)
+            # pose gradient is wanted; it is accumulated straight into the first three rows of the [4,4] result, whose
+            # fourth row the same call clears (GS2D_BWD_POSE_4X4): no fill kernel
+            g_w2c = torch.empty((4, 4), dtype=torch.float32, device=means3D.device)
             _r.rasterize_gaussians_backward(
                 rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix,
                 rs.tanfovx, rs.tanfovy, grad_color, grad_allmap, e, rs.sh_degree, rs.campos, geom, ctx.num_rendered, binning,

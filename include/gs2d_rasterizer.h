@@ -155,6 +155,10 @@ int gs2d_backward_posed(
  */
 #define GS2D_BWD_BLEND 1
 #define GS2D_BWD_PREPROCESS 2
+/* Together with both stages: dL_dpose points at SIXTEEN floats, a row-major 4x4 whose first three rows receive [dL/dR | dL/dt]
+ * and whose fourth row is cleared by the call as well -- the gradient of a [4,4] world-to-camera matrix
+ * (render/__init__.py:31-40 optimises such a matrix) without a separate fill of the buffer. */
+#define GS2D_BWD_POSE_4X4 4
 int gs2d_backward_staged(
     int stages, int g_begin, int g_end,
     int P, int D, int M, int R, const float* background, int width, int height, const float* means3D, const float* shs,
