@@ -120,3 +120,18 @@ def test_pixel_state_index_map_is_a_bijection():
     # the four lanes of a group are a 2x2 pixel block
     g0 = np.argwhere((idx // 4) == 5)
     assert g0[:, 0].max() - g0[:, 0].min() == 1 and g0[:, 1].max() - g0[:, 1].min() == 1
+
+
+def test_staged_backward_rejects_bad_stage_masks(hiplib):
+    """gs2d_backward_staged validates `stages` before it touches any buffer or the GPU: unknown bits, no stage at all, and
+    GS2D_BWD_POSE_4X4 (4) without both stages are errors with a message."""
+    nargs = len(hiplib.gs2d_backward_staged.argtypes)
+
+    def call(stages):
+        args = [stages, 0, 0] + [None if t in (C.c_void_p, C.c_char_p) else 0 for t in hiplib.gs2d_backward_staged.argtypes[3:]]
+        assert len(args) == nargs
+        return hiplib.gs2d_backward_staged(*args)
+
+    for bad in (0, 4, 8, 5, 6, 16 | 3):
+        assert call(bad) < 0, bad
+        assert b"stages" in hiplib.gs2d_last_error() or b"GS2D_BWD_POSE_4X4" in hiplib.gs2d_last_error()
