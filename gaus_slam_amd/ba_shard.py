@@ -221,6 +221,28 @@ class KeyframeShardedBA:
                 v.div_(self.world_size)
         return self.bucket.views
 
+    def _probe_overlap(self):
+        """The coalesced asynchronous collective is torch-internal API (dist._coalescing_manager).  Try it once, on scratch
+        rows, and let the ranks AGREE on the outcome (MAX all-reduce of a failure flag) before anyone changes its
+        collective pattern: if any rank's torch build rejects it, all ranks fall back together -- and permanently -- to one
+        all-reduce of the whole bucket after the backward."""
+        failed = 0
+        try:
+            scratch = GradBucket(8, self.bucket.flat.device)
+            scratch.reduce_rows(0, 8, self.group)
+            scratch.wait(self.group)
+        except Exception as ex:  # noqa: BLE001
+            failed = 1
+            import warnings
+            warnings.warn(f"overlapped chunk all-reduce unavailable on rank {self.rank} ({type(ex).__name__}: {ex})")
+        flag = torch.tensor([failed], dtype=torch.int32, device=self.bucket.flat.device)
+        if _collective(self.group):
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        if int(flag.item()):
+            self.overlap_chunks = 1
+        else:
+            self._overlap_ok = True
+
     def autotune(self, keyframes, candidates=(1, 2, 4), reps=10, warmup=3, margin=0.02):
         """Pick overlap_chunks by measurement on the machine at hand: one whole-bucket all-reduce after the backward (1) against
         chunked reductions overlapped with the per-Gaussian stage.  Chunking hides at most the length of that stage (26 us at
@@ -268,17 +290,13 @@ class KeyframeShardedBA:
         # Chunked, overlapped reduction: decided from GLOBAL facts only (every rank must issue the same collectives):
         # exactly one keyframe per rank, gradients written straight into the bucket.
         if self.direct_grads and self.overlap_chunks > 1 and len(keyframes) == self.world_size and self.params["means3D"].is_cuda:
-            try:
+            if not self._overlap_ok:
+                self._probe_overlap()
+            if self.overlap_chunks > 1:
+                # after the probe every rank has agreed that the chunked form works: a failure from here on is re-raised
+                # (the job ends non-zero) instead of letting one rank fall back alone while the others keep issuing
+                # chunked collectives -- a mismatch that would deadlock
                 return self._step_overlapped(mine[0], P)
-            except Exception as ex:  # noqa: BLE001
-                # The coalesced asynchronous collective is torch-internal API (dist._coalescing_manager).  Should this torch
-                # build reject it, the failure is the same on every rank and happens before anything was communicated in this
-                # step: fall back, permanently, to one all-reduce of the whole bucket after the backward.
-                if self._overlap_ok or self.bucket._pending:
-                    raise
-                import warnings
-                warnings.warn(f"overlapped chunk all-reduce unavailable ({type(ex).__name__}: {ex}); using one all-reduce per step")
-                self.overlap_chunks = 1
         if not mine:
             self.bucket.flat.zero_()
         elif len(mine) > 1 and self.n_streams > 1 and self.params["means3D"].is_cuda:

@@ -94,28 +94,52 @@ struct PinnedWord {
     ~PinnedWord() { if (p) (void)hipHostFree(p); }
 };
 thread_local PinnedWord g_pinned;
-// previous forward's num_rendered for the same problem shape: sizes the early binning allocation (a guess only: the
-// chunk is re-requested with the exact size when the guess was too small)
-// Geometry chunks whose gradient accumulator (grad_rec) is known to be all zero: the forward's blend kernel clears it with
-// spare store slots, so the first backward on that chunk needs no memset (7 us on the critical path at 500k Gaussians).
-// A chunk enters when its forward launched the blend kernel and leaves when a forward starts on it or a backward takes it; a
-// backward that does not find its chunk here (second backward on the same forward, R == 0, more than 8 forwards in
-// flight) clears the accumulator itself.
-struct CleanChunks {
+// Forward records.  The three scratch chunks carry no header a host could read without a device round trip, and the
+// backward's signature (the reference's, rasterizer.h:73-107) has no chunk sizes, so the library remembers what it needs
+// about the forwards whose backward may still come, keyed by the geometry chunk's address:
+//   * `det`, `R`, `bin`, `bin_bytes`: the mode the forward sized the binning chunk for and how large the allocator made
+//     it.  The backward lays the chunk out with the FORWARD's mode and refuses to run (gs2d_last_error) when the live
+//     gs2d_set_deterministic flag disagrees with it, when R or the binning pointer are not the forward's, or when the chunk
+//     is smaller than the layout it is asked to use -- a deterministic backward never runs on a chunk this table does
+//     not vouch for, so the 320 B x R of partial records can never land outside the chunk;
+//   * `clean`: the gradient accumulator (grad_rec) inside the geometry chunk is known to be all zero -- the forward's
+//     blend kernel clears it with spare store slots, so the first backward on that forward needs no memset (7 us on the
+//     critical path at 500k Gaussians).  Contract (include/gs2d_rasterizer.h): the chunks are opaque and must not be
+//     written, copied over or relocated between a forward and its backward.
+// A record enters when its forward has launched the blend kernel and leaves when a later forward is handed the same
+// geometry address; with more than 64 forwards in flight the oldest record is overwritten (its backward then clears the
+// accumulator itself and cannot run in deterministic mode).
+struct FwdRecord {
+    const void* geom = nullptr;
+    const void* bin = nullptr;
+    size_t bin_bytes = 0;
+    int det = 0, R = 0, P = 0;
+    bool clean = false;
+};
+struct FwdTable {
+    static constexpr int N = 64;
     std::mutex m;
-    const void* p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    FwdRecord e[N];
     int next = 0;
-    void drop(const void* q) { std::lock_guard<std::mutex> l(m); for (auto& e : p) if (e == q) e = nullptr; }
-    void add(const void* q) { std::lock_guard<std::mutex> l(m); p[next] = q; next = (next + 1) & 7; }
-    bool take(const void* q)
+    void drop(const void* geom) { std::lock_guard<std::mutex> l(m); for (auto& r : e) if (r.geom == geom) r = FwdRecord(); }
+    void add(const FwdRecord& r) { std::lock_guard<std::mutex> l(m); e[next] = r; next = (next + 1) % N; }
+    // copy of the record of `geom` (false: unknown chunk); take_clean also hands over the "accumulator is zero" token
+    bool find(const void* geom, bool take_clean, FwdRecord* out)
     {
         std::lock_guard<std::mutex> l(m);
-        for (auto& e : p) if (e == q) { e = nullptr; return true; }
+        for (auto& r : e)
+            if (r.geom == geom && geom != nullptr) {
+                *out = r;
+                if (take_clean) r.clean = false;
+                return true;
+            }
         return false;
     }
 };
-CleanChunks g_clean;
+FwdTable g_fwd;
 
+// previous forward's num_rendered for the same problem shape: sizes the early binning allocation (a guess only: the
+// chunk is re-requested with the exact size when the guess was too small)
 struct LastCount { int P = -1, W = 0, H = 0; uint32_t R = 0; };
 thread_local LastCount g_last;
 
@@ -205,10 +229,14 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
         return fail_msg("provide scales+rotations or transMat_precomp");
     if (colors_precomp == nullptr && (M <= 0 || (D + 1) * (D + 1) > M)) return fail_msg("sh degree exceeds coefficients");
 
+    // hipGetLastError is per host thread and keeps the last failure until it is read: drop whatever another library (or an
+    // earlier, already reported call) left behind, so that the checks below only ever see this call's launches.  A device
+    // that is truly lost fails the next launch again.
+    (void)hipGetLastError();
     const GeomLayout GL = geom_layout(P);
     char* geom = (char*)geometry_alloc(geometry_user, GL.total);
     if (!geom) return fail_msg("geometry allocation failed");
-    g_clean.drop(geom);
+    g_fwd.drop(geom);
     const ImgLayout IL = img_layout(width, height);
 
     CamParams cam;
@@ -254,13 +282,20 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     }
     // From here on the scan kernel WILL store into the pinned word, so every return path first waits for that store
     // (a later forward on this thread would otherwise reset the sentinel and could pick up this call's stale total).
+    // Poll, then yield: the store normally lands within tens of microseconds (preprocess + block-sum scan), so the thread
+    // spins with `pause` for at most ~100 us; if the stream is backed up behind earlier work (or several ranks share the
+    // host's cores) it hands its time slice back between looks instead of burning a core per rank.
     auto wait_total = [&]() -> bool {
         const auto t0 = std::chrono::steady_clock::now();
         uint64_t spins = 0;
+        bool yielding = false;
         while (*pinned == 0xFFFFFFFFu) {
-            cpu_relax();
-            if ((++spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2))
-                return hipStreamSynchronize(s) == hipSuccess && *pinned != 0xFFFFFFFFu;
+            if (yielding) std::this_thread::yield(); else cpu_relax();
+            if ((++spins & (yielding ? 0x3Fu : 0x3FFu)) == 0) {
+                const auto dt = std::chrono::steady_clock::now() - t0;
+                if (dt > std::chrono::seconds(2)) return hipStreamSynchronize(s) == hipSuccess && *pinned != 0xFFFFFFFFu;
+                if (dt > std::chrono::microseconds(100)) yielding = true;
+            }
         }
         return true;
     };
@@ -284,8 +319,10 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
 
     g_last.P = P; g_last.W = width; g_last.H = height; g_last.R = num_rendered_u;
     const BinLayout BL = bin_layout(R, det);  // offsets always follow the true count; the chunk may be larger than BL.total
-    char* bin = (bin_pre && BL.total <= pre_bytes) ? bin_pre : (char*)binning_alloc(binning_user, BL.total);
+    const bool reuse_pre = bin_pre && BL.total <= pre_bytes;
+    char* bin = reuse_pre ? bin_pre : (char*)binning_alloc(binning_user, BL.total);
     if (!bin) return fail_msg("binning allocation failed");
+    const size_t bin_bytes = reuse_pre ? pre_bytes : BL.total;
     uint32_t* point_list = (uint32_t*)(bin + BL.point_list);
     uint8_t* hits = (uint8_t*)(bin + BL.hits);
     uint8_t* hits4 = (uint8_t*)(bin + BL.hits4);
@@ -335,7 +372,11 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     g_timer.begin(ST_BLEND_FWD, s);
     gs2d::launch_blend_fwd(width, height, ranges, point_list, rec, background, out_color, out_others, pix_state, hits, hits4,
                            use_sa, (float4*)(geom + GL.grad_rec), (size_t)P * (GS2D_GRAD_FLOATS / 4), s);
-    g_clean.add(geom);
+    {
+        FwdRecord fr;
+        fr.geom = geom; fr.bin = bin; fr.bin_bytes = bin_bytes; fr.det = det ? 1 : 0; fr.R = R; fr.P = P; fr.clean = true;
+        g_fwd.add(fr);
+    }
     g_timer.end(ST_BLEND_FWD, s);
     GS2D_STAGE("blend_fwd");
     return R;
@@ -380,14 +421,38 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
     // The pose gradient is accumulated by the preprocess stage(s) and cleared once, by the call that runs the blend stage:
     // inside blend_bwd_kernel when that kernel runs (one launch less on the tracking loop's critical path), else by a memset.
     const int pose_floats = (stages & GS2D_BWD_POSE_4X4) != 0 ? 16 : 12;
-    if (dL_dpose != nullptr && (stages & 1) != 0 && (P <= 0 || R <= 0 || g_deterministic.load() != 0))
-        GS2D_CHECK(hipMemsetAsync(dL_dpose, 0, sizeof(float) * pose_floats, s), "memset dL_dpose");
-    if (P <= 0) return 0;
+    if (P <= 0) {
+        if (dL_dpose != nullptr && (stages & 1) != 0)
+            GS2D_CHECK(hipMemsetAsync(dL_dpose, 0, sizeof(float) * pose_floats, s), "memset dL_dpose");
+        return 0;
+    }
     if (g_begin < 0 || g_end > P || g_begin > g_end) return fail_msg("bad Gaussian range");
     if (!geom_buffer || !img_buffer || (R > 0 && !binning_buffer)) return fail_msg("missing forward state");
-    const bool det = g_deterministic.load() != 0;  // the forward sized the binning chunk for it (same flag required)
+    // The mode the FORWARD ran in decides the layout of the binning chunk (see FwdTable): never the live flag alone.
+    const bool live_det = g_deterministic.load() != 0;
+    FwdRecord fr;
+    const bool known = g_fwd.find(geom_buffer, /*take_clean=*/(stages & 1) != 0, &fr);
+    if (known && fr.P != P) return fail_msg("P is not the Gaussian count of the forward that produced this geometry chunk");
+    if ((stages & 1) != 0) {
+        if (known) {
+            if (fr.R != R) return fail_msg("R is not the num_rendered of the forward that produced this geometry chunk");
+            if (R > 0 && fr.bin != (const void*)binning_buffer)
+                return fail_msg("binning_buffer is not the chunk the forward of this geometry chunk was given");
+            if ((fr.det != 0) != live_det)
+                return fail_msg("gs2d_set_deterministic changed between this forward and its backward (the forward sizes the "
+                                "binning chunk for the mode it runs in): restore the flag or rerun the forward");
+        } else if (live_det) {
+            return fail_msg("deterministic backward on a geometry chunk without a forward record (relocated chunk, or more "
+                            "than 64 forwards in flight): its binning chunk cannot be vouched for");
+        }
+    }
+    const bool det = known ? fr.det != 0 : false;
+    if (dL_dpose != nullptr && (stages & 1) != 0 && (R <= 0 || det))
+        GS2D_CHECK(hipMemsetAsync(dL_dpose, 0, sizeof(float) * pose_floats, s), "memset dL_dpose");
     const GeomLayout GL = geom_layout(P);
     const BinLayout BL = bin_layout(R, det);
+    if (known && (stages & 1) != 0 && R > 0 && BL.total > fr.bin_bytes)
+        return fail_msg("binning chunk is smaller than the layout of this backward");
     const ImgLayout IL = img_layout(width, height);
     const float4* rec = (const float4*)(geom_buffer + GL.rec);
     const uint8_t* clamped = (const uint8_t*)(geom_buffer + GL.clamped);
@@ -398,7 +463,7 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
     const float* pix_state = (const float*)(img_buffer + IL.pix);
 
     if ((stages & 1) != 0 && !det) {
-        if (!g_clean.take(geom_buffer))  // else: cleared by the forward's blend kernel, nothing has touched it since
+        if (!(known && fr.clean))  // else: cleared by the forward's blend kernel, nothing has touched it since
             GS2D_CHECK(hipMemsetAsync(grad_rec, 0, sizeof(float) * GS2D_GRAD_FLOATS * (size_t)P, s), "memset grad_rec");
         if (R > 0) {
             g_timer.begin(ST_BLEND_BWD, s);
@@ -412,7 +477,7 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         // no atomics: per-(instance, quadrant) partial records, then a fixed-order sum per Gaussian (gs2d_det.hip)
         float* det_slots = (float*)(binning_buffer + BL.det_slots);
         uint32_t* det_inv = (uint32_t*)(binning_buffer + BL.det_inv);
-        (void)g_clean.take(geom_buffer);  // det_reduce overwrites the accumulator: no longer "known zero"
+        // (the record's clean token was taken above: det_reduce overwrites the accumulator, it is no longer "known zero")
         g_timer.begin(ST_BLEND_BWD, s);
         if (R > 0) {
             GS2D_CHECK(hipMemsetAsync(det_slots, 0, sizeof(float) * GS2D_GRAD_FLOATS * 4 * (size_t)R, s), "memset det_slots");
@@ -440,7 +505,10 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         gs2d::launch_preprocess_bwd(g_begin, g_end, D, M, means3D, rec, radii, shs, clamped, scales, rotations, cam, grad_rec,
                                     dL_dtransMat, dL_dnormal, dL_dcolor, dL_dopacity, dL_dsh, dL_dmean2D, dL_dmean3D,
                                     dL_dscale, dL_drot, pose_Rt, pose_quat, pose_Rt ? dL_dpose : nullptr,
-                                    /*need_record=*/scale_modifier != 1.0f, s);
+                                    /*need_record=*/scale_modifier != 1.0f,
+                                    // deterministic mode: per-workgroup partials in the geometry chunk's depth array (4 B
+                                    // per Gaussian, dead once the forward's duplicate stage has run; 48 B per 256 Gaussians needed)
+                                    (live_det && pose_Rt) ? (float*)(geom_buffer + GL.depths) : nullptr, s);
         g_timer.end(ST_PREPROCESS_BWD, s);
         GS2D_STAGE("preprocess_bwd");
     }

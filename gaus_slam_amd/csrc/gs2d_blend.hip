@@ -12,13 +12,16 @@
 //     wave-private LDS in batches and give every group its own depth-ordered queue of slot numbers (a byte list in
 //     LDS): each loop trip the groups composite different splats, records read back as per-group LDS broadcasts,
 //     prefetched one trip ahead;
-//   * backward: per-(pixel,splat) gradients are summed over the 16 lanes of a row with a 16-value DPP butterfly, added
-//     into per-splat accumulators in wave-private LDS (ds_add_f32) and flushed to the Gaussian's gradient record once
-//     per (quadrant, batch) -- the reference issues 16-18 scalar global atomics per (pixel, splat).
+//   * backward: per-(pixel,splat) gradients are summed over the 16 lanes of a row with a 16-value DPP butterfly and added
+//     into per-splat accumulators in wave-private LDS -- a plain read / add / store on trips whose four rows hold four
+//     different splats, ds_add_f32 only when two rows meet on a splat -- and every touched splat of a batch is flushed to
+//     its Gaussian's gradient record once per (quadrant, batch), one global float atomic per component (the reference
+//     issues 16-18 scalar global atomics per (pixel, splat)).
 // Arithmetic follows the oracle's expression order; the file is compiled with -ffp-contract=off so the
 // per-pixel recurrences reproduce the CPU oracle up to the ulp-level difference of v_exp_f32 / v_rcp_f32.
 #include "gs2d_common.h"
 #include "gs2d_cull.h"
+#include "gs2d_blend_dev.h"  // dev-only probes (wave profile, ingredient pricing): all pass-through in the product build
 
 #include <type_traits>
 
@@ -73,50 +76,6 @@ __device__ __forceinline__ void wave_lds_sync()
 #ifndef GS2D_FWD_WAVES_PER_EU
 #define GS2D_FWD_WAVES_PER_EU GS2D_WAVES_PER_EU
 #endif
-// Dev-only experiment hooks (scripts/dev/variants.sh builds variants with -DGS2D_EXPERIMENT=n; results are WRONG by
-// design, they only price one ingredient of blend_bwd via scripts/dev/stage_ms.py).  All pass-through in the product
-// build.  1: no global atomics in the flush   2: no butterfly   4: no flush loop   5: plain LDS store instead of ds_add_f32
-#if defined(GS2D_EXPERIMENT) && GS2D_EXPERIMENT == 1
-#define GS2D_EXP_ATOMIC(X) if (va == 123.456f) grad_rec[flush_off] = vb;
-#else
-#define GS2D_EXP_ATOMIC(X) X
-#endif
-#if defined(GS2D_EXPERIMENT) && GS2D_EXPERIMENT == 4
-#define GS2D_EXP_FLUSH(T) ((T) && f0 == 12345)
-#else
-#define GS2D_EXP_FLUSH(T) (T)
-#endif
-#if defined(GS2D_EXPERIMENT) && GS2D_EXPERIMENT == 5
-#define GS2D_EXP_LDSADD(P, V) *(P) = (V)
-#else
-#define GS2D_EXP_LDSADD(P, V) atomicAdd(P, V)
-#endif
-#if defined(GS2D_EXPERIMENT) && GS2D_EXPERIMENT == 2
-#define GS2D_EXP_BUTTERFLY tot = (g[0] + g[3]) + (g[9] + g[15]) + g[1] + g[2] + g[4] + g[5] + g[6] + g[7] + g[8] + g[10] + g[11]; if (false)
-#else
-#define GS2D_EXP_BUTTERFLY
-#endif
-#ifdef GS2D_PROFILE_WAVES
-// dev-only instrumentation (scripts/dev/wave_profile.py): per wave [start, end, trips, hw_id] for the last launch
-__device__ unsigned long long g_wave_prof[2][4 * 8192 * 4];
-#define GS2D_PROF_BEGIN() const unsigned long long prof_t0 = wall_clock64(); unsigned int prof_trips = 0; unsigned long long prof_stage = 0, prof_s0 = 0
-#define GS2D_PROF_TRIP() prof_trips++
-#define GS2D_PROF_STAGE_BEGIN() prof_s0 = __builtin_amdgcn_s_memtime()
-#define GS2D_PROF_STAGE_END() prof_stage += __builtin_amdgcn_s_memtime() - prof_s0
-#define GS2D_PROF_END(K)                                                                                             \
-    if (lane == 0 && blockIdx.x < 8192) {                                                                            \
-        unsigned long long* pp = g_wave_prof[K] + ((size_t)blockIdx.x * 4 + wave) * 4;                               \
-        pp[0] = prof_t0; pp[1] = wall_clock64(); pp[2] = prof_trips | (prof_stage << 32); /* staging time in shader cycles */                                                 \
-        pp[3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); \
-    }
-#else
-#define GS2D_PROF_BEGIN()
-#define GS2D_PROF_TRIP()
-#define GS2D_PROF_STAGE_BEGIN()
-#define GS2D_PROF_STAGE_END()
-#define GS2D_PROF_END(K)
-#endif
-
 // ------------------------------------------------------------------------------------------- queue helpers
 __device__ __forceinline__ int row_select(int row8, int j0, int j1, int j2, int j3)
 {
@@ -529,14 +488,14 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
 //
 // One wave per 8x8 quadrant, waves independent (wave-private LDS staging, no workgroup barrier).  Per contributing
 // (row, splat) pair the 16 main components are reduced over the row's 16 lanes with the butterfly above, added into the
-// splat's LDS accumulators, and flushed to the Gaussian's record once per (quadrant, batch) by one global atomic
-// instruction whose lanes cover four records' contiguous bytes (the reference issues 16-18 scalar atomics per
-// (pixel, splat) pair).
+// splat's LDS accumulators (plain store or LDS atomic, see GS2D_BWD_ACC_PRE below), and flushed to the Gaussian's record
+// once per (quadrant, batch): per flush pass one global-atomic instruction per touched component, its lanes covering four
+// records (the reference issues 16-18 scalar atomics per (pixel, splat) pair).
 // Wave-private LDS of the backward: a 64-byte staged record per splat of the batch (Tu|cx, Tv|cy, Tw|opacity,
 // r,g,b,id -- the normal is fetched from global memory only by waves that carry normal gradients) and 13 gradient
 // accumulators per splat (3 colour, 9 dT, 1 opacity).  The gradient atomics are the backward's scarcest resource
 // (scripts/dev/atomic_bench.hip: the kernel's former atomic stream alone takes ~360 us on the whole chip), so every
-// (row, splat) contribution is first added into LDS (GS2D_BWD_LDS_ACCUM below) and each touched splat of the batch is flushed to its
+// (row, splat) contribution is first summed in LDS (GS2D_BWD_LDS_ACCUM below) and each touched splat of the batch is flushed to its
 // global record ONCE per (quadrant, batch) -- about half as many global atomics, three quarters of a workgroup's LDS
 // budget (29.6 KB, 5 workgroups per CU).
 //
@@ -584,9 +543,7 @@ __device__ __forceinline__ uint32_t least_pair_xor(uint32_t a, uint32_t b, uint3
                    jc_ = __builtin_amdgcn_readlane(JJ, 32), jd_ = __builtin_amdgcn_readlane(JJ, 48);                    \
     /* an exhausted row reads its own end marker (252 + row), so two of those never look like a shared splat */         \
     const bool clash_ = least_pair_xor(ja_, jb_, jc_, jd_) == 0u;
-#ifdef GS2D_EXPERIMENT
-#define GS2D_BWD_LDS_ACCUM(JJ, V) if ((V) != 0.f) GS2D_EXP_LDSADD(&wb.acc[((JJ) & 63) * NACC + acc_comp], V);
-#else
+#ifndef GS2D_BWD_LDS_ACCUM  // (gs2d_blend_dev.h may have replaced it in an experiment build)
 #define GS2D_BWD_LDS_ACCUM(JJ, V)                                                                                       \
     if ((V) != 0.f) {                                                                                                   \
         if (clash_) atomicAdd(&wb.acc[ai_], V);                                                                         \

@@ -173,13 +173,14 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
                            const float* transMat_precomp, const float* colors_precomp, const CamParams& cam,
                            int* radii, float* depths, float4* rec, uint32_t* tiles_touched, ushort4* rect, uint8_t* clamped,
                            const float* pose_Rt, const float* pose_q, uint32_t* block_sums, hipStream_t s);
-// Gaussians [first, P)
+// Gaussians [first, P).  pose_partials (deterministic mode, else NULL): room for 12 floats per workgroup of the launch
+// (<= ceil((P - first) / 256) workgroups); the pose gradient is then summed in a fixed order instead of with atomics
 void launch_preprocess_bwd(int first, int P, int D, int M, const float* means3D, const float4* rec, const int* radii,
                            const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
                            const CamParams& cam, const float* grad_rec, float* dL_dtransMat, float* dL_dnormal,
                            float* dL_dcolor, float* dL_dopacity, float* dL_dsh, float* dL_dmean2D,
                            float* dL_dmean3D, float* dL_dscale, float* dL_drot, const float* pose_Rt, const float* pose_q,
-                           float* dL_dpose, int need_record, hipStream_t s);
+                           float* dL_dpose, int need_record, float* pose_partials, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
 void launch_pose_quat(const float* pose_Rt, float* q_out, hipStream_t s);
 // inclusive scan of n u32; tmp must hold ceil(n/1024)+64 u32. If total_out != nullptr the grand total is stored there.

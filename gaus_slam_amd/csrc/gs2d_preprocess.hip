@@ -566,7 +566,8 @@ preprocess_bwd_kernel(int first, int P, int D, int M, const float* __restrict__ 
                       float* __restrict__ dL_dtransMat, float* __restrict__ dL_dnormal, float* __restrict__ dL_dcolor,
                       float* __restrict__ dL_dopacity, float* __restrict__ dL_dsh, float* __restrict__ dL_dmean2D,
                       float* __restrict__ dL_dmean3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
-                      const float* __restrict__ pose_Rt, const float* __restrict__ pose_q, float* __restrict__ dL_dpose)
+                      const float* __restrict__ pose_Rt, const float* __restrict__ pose_q, float* __restrict__ dL_dpose,
+                      float* __restrict__ pose_partials)
 {
     // P = one past the last Gaussian of this launch's range.  One Gaussian per thread; with a pose the grid is capped and
     // the threads stride over the range, so that fewer workgroups queue up on the 12 pose-gradient words.
@@ -591,8 +592,23 @@ preprocess_bwd_kernel(int first, int P, int D, int M, const float* __restrict__ 
         __syncthreads();
         if (threadIdx.x < 12) {
             const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-            if (v != 0.f) atomicAdd(dL_dpose + threadIdx.x, v);
+            // deterministic mode: one partial per workgroup, summed in a fixed order by pose_reduce_kernel
+            if (pose_partials != nullptr) pose_partials[blockIdx.x * 12 + threadIdx.x] = v;
+            else if (v != 0.f) atomicAdd(dL_dpose + threadIdx.x, v);
         }
+    }
+}
+
+// Deterministic pose gradient: dL_dpose[c] += sum over the workgroups' partials, always in the same order (lane l adds
+// partials l, l + 64, ... one after the other, then a fixed butterfly over the 64 lanes).
+__global__ void __launch_bounds__(64) pose_reduce_kernel(int n, const float* __restrict__ partials, float* __restrict__ dL_dpose)
+{
+    for (int c = 0; c < 12; c++) {
+        float v = 0.f;
+        for (int i = threadIdx.x; i < n; i += 64) v += partials[i * 12 + c];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (threadIdx.x == 0) dL_dpose[c] += v;
     }
 }
 
@@ -628,7 +644,7 @@ void launch_preprocess_bwd(int first, int P, int D, int M, const float* means3D,
                            const CamParams& cam, const float* grad_rec, float* dL_dtransMat, float* dL_dnormal,
                            float* dL_dcolor, float* dL_dopacity, float* dL_dsh, float* dL_dmean2D,
                            float* dL_dmean3D, float* dL_dscale, float* dL_drot, const float* pose_Rt, const float* pose_q,
-                           float* dL_dpose, int need_record, hipStream_t s)
+                           float* dL_dpose, int need_record, float* pose_partials, hipStream_t s)
 {
     if (P <= first) return;
     // The per-Gaussian code needs the forward's Tw.z (record word 10).  With scales / rotations and scale_modifier == 1 it
@@ -644,7 +660,10 @@ void launch_preprocess_bwd(int first, int P, int D, int M, const float* means3D,
     if (dL_dpose != nullptr && grid > 1024) grid = max(1024 / (GS2D_POSE_GPT / 2), (grid + GS2D_POSE_GPT - 1) / GS2D_POSE_GPT);
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(grid), dim3(256), 0, s, first, P, D, M, means3D, rec, radii, shs,
                        clamped, scales, rotations, cam, grad_rec, dL_dtransMat, dL_dnormal, dL_dcolor, dL_dopacity,
-                       dL_dsh, dL_dmean2D, dL_dmean3D, dL_dscale, dL_drot, pose_Rt, pose_q, dL_dpose);
+                       dL_dsh, dL_dmean2D, dL_dmean3D, dL_dscale, dL_drot, pose_Rt, pose_q, dL_dpose,
+                       dL_dpose != nullptr ? pose_partials : nullptr);
+    if (dL_dpose != nullptr && pose_partials != nullptr)
+        hipLaunchKernelGGL(pose_reduce_kernel, dim3(1), dim3(64), 0, s, grid, pose_partials, dL_dpose);
 }
 
 void launch_pose_quat(const float* pose_Rt, float* q_out, hipStream_t s)

@@ -22,9 +22,16 @@
  *     matrices render/render_2dgs.py:10-24 builds);
  *   - scratch memory is obtained through caller-supplied allocator callbacks
  *     (the C form of the reference's std::function<char*(size_t)>); the three
- *     chunks must stay alive, untouched, until the matching gs2d_backward;
- *     their internal layout is private to this library (query it with the
- *     gs2d_*_layout helpers, used by the parity tests only);
+ *     chunks are OPAQUE and must stay alive, unwritten and at the same address
+ *     until the matching gs2d_backward: the library keeps a host-side record per
+ *     forward (keyed by the geometry chunk's address) that says which mode the
+ *     binning chunk was sized for and that the gradient accumulator inside the
+ *     geometry chunk is still zero.  A backward on a chunk without a record (a
+ *     copy at another address, more than 64 forwards in flight) clears the
+ *     accumulator itself and cannot run in deterministic mode; a backward whose
+ *     R / binning pointer / deterministic flag differ from its forward's returns
+ *     an error instead of touching memory.  The internal layout is private
+ *     (query it with the gs2d_*_layout helpers, used by the parity tests only);
  *   - `stream` is a hipStream_t (NULL = the null stream).  The reference used
  *     the legacy default stream; callers here pass torch's current HIP stream;
  *   - return value < 0 signals an error; gs2d_last_error() describes it.
@@ -175,7 +182,10 @@ int gs2d_backward_staged(
  * library's by default.  With the switch on, the backward uses no atomics: every (instance, quadrant) pair is summed by
  * one wave into a record of its own and a Gaussian's records are added in a fixed order -- two runs on the same inputs give
  * bit-identical gradients (tests/test_gpu_round2.py).  Slower (about 2x for the backward) and 324 B more scratch per tile
- * instance.  The switch must not change between a forward and its backward: the forward sizes the binning chunk for it.
+ * instance.  The forward sizes the binning chunk for the mode it runs in and records that mode; a backward called with the
+ * switch in the other position fails with an error (nothing is launched) -- restore the switch or rerun the forward.
+ * Exception: the POSE gradient (dL_dpose of the *_posed / *_staged calls) is summed with 12 float atomics per workgroup in
+ * either mode, so its last bits may still differ from run to run.
  */
 void gs2d_set_deterministic(int on);
 int gs2d_get_deterministic(void);

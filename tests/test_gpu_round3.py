@@ -1,0 +1,148 @@
+"""Round-3 GPU tests: the forward records behind the mode flags (deterministic / binning) and the "accumulator is
+clean" token, exercised the ways a caller can get them wrong."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ["dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"]
+
+
+def _grads(W, H, seed=0):
+    dc, da = util.make_upstream_grads(W, H, seed=seed, channels=(0, 1, 2, 3, 4, 5, 6))
+    return (dc * W * H).numpy(), (da * W * H).numpy()
+
+
+def test_deterministic_flag_toggled_between_forward_and_backward_is_an_error():
+    """The forward sizes the binning chunk for the mode it runs in (deterministic mode appends 320 B x R of partial
+    records).  Switching gs2d_set_deterministic between a forward and its backward used to make the backward lay the chunk
+    out for the OTHER mode (writes past the end of the chunk when switched on).  Now the backward refuses with a message,
+    launches nothing, and the same forward state still gives the right gradients once the flag is restored."""
+    from gaus_slam_amd import rasterizer
+    W, H = 256, 192
+    sc = util.make_scene(6000, W, H, seed=7, regime="mapping")
+    dc, da = _grads(W, H)
+    assert not rasterizer.is_deterministic()
+    h = util.hip_forward(sc, binning="footprint")
+    rasterizer.set_deterministic(True)
+    try:
+        with pytest.raises(RuntimeError, match="gs2d_set_deterministic changed"):
+            util.hip_backward(h, dc, da)
+        hd = util.hip_forward(sc, binning="footprint")  # a forward sized for the deterministic backward
+        gd = util.hip_backward(hd, dc, da)
+    finally:
+        rasterizer.set_deterministic(False)
+    with pytest.raises(RuntimeError, match="gs2d_set_deterministic changed"):
+        util.hip_backward(hd, dc, da)  # ... and the other way round
+    g = util.hip_backward(h, dc, da)    # flag restored: the first forward's state is still good
+    for k in KEYS:
+        assert np.abs(g[k]).max() > 0, k
+        assert util.grad_err(g[k], gd[k]) <= 1e-5, k
+
+
+def test_backward_rejects_foreign_forward_state():
+    """R or the binning chunk of another forward, or a chunk this library never handed out in deterministic mode: errors,
+    not memory accesses."""
+    from gaus_slam_amd import rasterizer
+    W, H = 128, 96
+    sc = util.make_scene(1500, W, H, seed=8, regime="mapping")
+    dc, da = _grads(W, H)
+    h = util.hip_forward(sc, binning="footprint")
+    wrong_r = dict(h, num_rendered=h["num_rendered"] + 64)
+    with pytest.raises(RuntimeError, match="num_rendered"):
+        util.hip_backward(wrong_r, dc, da)
+    geom, binning, img = h["buffers"]
+    other_bin = dict(h, buffers=(geom, binning.clone(), img))
+    with pytest.raises(RuntimeError, match="binning_buffer"):
+        util.hip_backward(other_bin, dc, da)
+    # a relocated copy of all three chunks has no forward record: fine in the default mode (the backward clears the
+    # accumulator itself) ...
+    moved = dict(h, buffers=(geom.clone(), binning.clone(), img.clone()))
+    g_ref = util.hip_backward(h, dc, da)
+    g_moved = util.hip_backward(moved, dc, da)
+    for k in KEYS:
+        assert util.grad_err(g_moved[k], g_ref[k]) <= 1e-5, k
+    # ... refused in deterministic mode (nothing vouches for the size of that binning chunk)
+    rasterizer.set_deterministic(True)
+    try:
+        with pytest.raises(RuntimeError, match="without a forward record"):
+            util.hip_backward(moved, dc, da)
+    finally:
+        rasterizer.set_deterministic(False)
+
+
+def test_clean_accumulator_token_survives_interleaving():
+    """The first backward on a forward skips the memset of the gradient accumulator because the forward's blend kernel
+    cleared it.  That knowledge is host-side state keyed by the geometry chunk's address, so: interleave no-grad renders,
+    forwards of other sizes whose chunks recycle freed addresses, several forwards alive at once with their backwards in
+    the opposite order, and a backward on a side stream -- every gradient must equal the one a fresh forward+backward of
+    the same scene gives."""
+    W, H = 192, 128
+    dc, da = _grads(W, H, seed=3)
+    scenes = [util.make_scene(P, W, H, seed=60 + i, regime="mapping") for i, P in enumerate((3000, 5000, 3000, 800))]
+
+    def fresh(sc):
+        return util.hip_backward(util.hip_forward(sc, binning="footprint"), dc, da)
+
+    ref = [fresh(sc) for sc in scenes]
+    torch.cuda.empty_cache()
+    # forwards alive at once, backwards in the opposite order, a dropped (no-grad) render in between each
+    hs = []
+    for sc in scenes:
+        hs.append(util.hip_forward(sc, binning="footprint"))
+        dropped = util.hip_forward(scenes[3], binning="footprint")  # its chunks go back to the allocator right away
+        del dropped
+    for i in reversed(range(len(scenes))):
+        g = util.hip_backward(hs[i], dc, da)
+        for k in KEYS:
+            assert util.grad_err(g[k], ref[i][k]) <= 1e-5, (i, k)
+    # a second backward on every state (token already taken), after other forwards recycled memory
+    del g
+    for i in range(len(scenes)):
+        util.hip_forward(scenes[(i + 1) % 4], binning="footprint")
+        g = util.hip_backward(hs[i], dc, da)
+        for k in KEYS:
+            assert util.grad_err(g[k], ref[i][k]) <= 1e-5, (i, k)
+    # backward on a side stream (ordered after the forward by an event)
+    h = util.hip_forward(scenes[1], binning="footprint")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = util.hip_backward(h, dc, da)
+    side.synchronize()
+    for k in KEYS:
+        assert util.grad_err(g[k], ref[1][k]) <= 1e-5, k
+
+
+def test_deterministic_pose_gradient_is_bit_identical():
+    """in deterministic mode the pose gradient (tracking regime) is summed from per-workgroup partials in a
+    fixed order instead of with float atomics -- two runs agree bit for bit and match the atomic path."""
+    from gaus_slam_amd import rasterizer, render as gs_render, tracking
+    from gaus_slam_amd.scene_synth import random_w2c
+    dev = torch.device("cuda", 0)
+    W, H, P = 320, 240, 70000
+    sc = util.make_scene(P, W, H, seed=12, regime="tracking")
+    st = gs_render.settings_from_camera(sc["cam"], dev, use_sa=True)
+    p = {k: sc[k].to(dev) for k in ("means3D", "opacities", "scales", "rotations", "colors")}
+    dc, da = util.make_upstream_grads(W, H, seed=2, channels=(0, 1, 5, 6))
+    dc, da = (dc * W * H).to(dev), (da * W * H).to(dev)
+    w2c0 = random_w2c(np.random.default_rng(5), 2.0, 0.05).to(dev)
+
+    def pose_grad():
+        w2c = w2c0.clone().requires_grad_(True)
+        pkg = tracking.render_tracking(st, w2c, p["means3D"], p["opacities"], p["colors"], p["scales"], p["rotations"])
+        torch.autograd.backward([pkg["render_color"], pkg["allmap"]], [dc, da])
+        return w2c.grad.cpu().numpy().copy()
+
+    g_atomic = pose_grad()
+    rasterizer.set_deterministic(True)
+    try:
+        g1, g2, g3 = pose_grad(), pose_grad(), pose_grad()
+    finally:
+        rasterizer.set_deterministic(False)
+    assert np.abs(g1[:3]).max() > 0 and np.all(g1[3] == 0)
+    assert np.array_equal(g1.view(np.uint32), g2.view(np.uint32)) and np.array_equal(g1.view(np.uint32), g3.view(np.uint32))
+    assert np.abs(g1 - g_atomic).max() <= 1e-4 * np.abs(g_atomic).max()

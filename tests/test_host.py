@@ -135,3 +135,32 @@ def test_staged_backward_rejects_bad_stage_masks(hiplib):
     for bad in (0, 4, 8, 5, 6, 16 | 3):
         assert call(bad) < 0, bad
         assert b"stages" in hiplib.gs2d_last_error() or b"GS2D_BWD_POSE_4X4" in hiplib.gs2d_last_error()
+
+
+def test_deterministic_backward_refuses_chunks_without_a_forward_record(hiplib):
+    """The deterministic backward appends 320 B x R of partial records to the binning chunk, so it only ever runs on a chunk
+    whose forward this library recorded (mode, R, size).  With the flag on, a backward on unknown chunks must fail with a
+    message BEFORE anything is launched or written -- checkable without a GPU because the pointers are never touched."""
+    argt = hiplib.gs2d_backward_staged.argtypes
+    names_at = {3: 1000, 6: 5000, 8: 64, 9: 48}  # P, R, width, height
+    args = [1, 0, 0] + [(None if t in (C.c_void_p, C.c_char_p) else 0) for t in argt[3:]]
+    for k, v in names_at.items():
+        args[k] = v
+    fake = (C.c_char * 64)()
+    addr = C.addressof(fake)
+    # geom_buffer, binning_buffer, img_buffer: positions of the three char* arguments
+    char_ps = [i for i, t in enumerate(argt) if t is C.c_char_p]
+    ptr_args = list(args)
+    if char_ps:
+        for i in char_ps:
+            ptr_args[i] = C.cast(addr, C.c_char_p)
+    else:  # all pointers are void*: geom/binning/img follow `radii`
+        base = 3 + 20
+        for i in range(base, base + 3):
+            ptr_args[i] = addr
+    hiplib.gs2d_set_deterministic(1)
+    try:
+        assert hiplib.gs2d_backward_staged(*ptr_args) < 0
+        assert b"without a forward record" in hiplib.gs2d_last_error()
+    finally:
+        hiplib.gs2d_set_deterministic(0)
