@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--keyframes-per-gpu", type=int, default=1, help="keyframes each rank renders per step (default 1 = the "
                     "headline metric); rendered one after the other unless --streams 2")
+    ap.add_argument("--no-batch", action="store_true", help="--keyframes-per-gpu > 1: render a rank's keyframes one operator call "
+                    "after the other instead of one batched call (gs2d_forward_batch / gs2d_backward_batch)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams a rank spreads its keyframes over (ba_shard.KeyframeShardedBA)")
     ap.add_argument("--prewarm-steps", type=int, default=PREWARM_STEPS, help="upper bound on the untimed steps before the warm-up that take "
                     "the GPU out of its idle clocks (about 1.6 s worth are run; 0 = none); the count is reported in config.prewarm_steps")
@@ -246,19 +248,42 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
     dcolor, dallmap = dcolor.to(dev), dallmap.to(dev)
     settings = gs_render.settings_from_camera(cam, dev, use_sa=use_sa)
     last = {}
+    kf_settings = {}
 
     def render_fn(p, _kf):
         # gradient carrier only: neither the reference's extension (its Python wrapper does not even pass it down,
         # RAST/gaus_2dgs_rasterization/__init__.py:59-80) nor this library reads its values, so no fill kernel is spent on it
         means2D = torch.empty_like(p["means3D"]).requires_grad_(True)
-        pkg = gs_render.render(settings, p["means3D"], means2D, p["opacities"], colors_precomp=p["colors"],
+        pkg = gs_render.render(kf_settings.get(_kf) or settings, p["means3D"], means2D, p["opacities"], colors_precomp=p["colors"],
                                scales=p["scales"], rotations=p["rotations"])
         last["radius"] = pkg["radius"]
         return (pkg["render_color"], pkg["allmap"]), (dcolor, dallmap)
 
-    # gradients are produced directly in the all-reduce bucket whenever the bucket is consumed (N > 1, fused Adam)
-    ba = ba_shard.KeyframeShardedBA(params, render_fn, direct_grads=(_dist_on(world) or args.adam == "fused"), streams=args.streams)
     kpg = max(1, args.keyframes_per_gpu)
+    # several keyframes per rank: every rank renders ITS keyframes in one batched operator call (one blend grid over the
+    # tiles of all its frames).  Keyframe i of the step goes to rank i % world; each gets its own camera.
+    import numpy as np
+    for i in range(world * kpg):
+        if i < world:
+            kf_settings[i] = settings if i == rank else None
+        elif i % world == rank:
+            w2c_i = random_w2c(np.random.default_rng(2000 + i), max_rot_deg=3.0, max_trans=0.1) @ sc["cam"].w2c
+            kf_settings[i] = gs_render.settings_from_camera(setup_camera(W, H, sc["cam"].K, w2c_i), dev, use_sa=use_sa)
+
+    def render_batch_fn(p, kfs):
+        means2D = torch.empty_like(p["means3D"]).requires_grad_(True)
+        pkgs = gs_render.render_batch([kf_settings[k] for k in kfs], p["means3D"], means2D, p["opacities"],
+                                      colors_precomp=p["colors"], scales=p["scales"], rotations=p["rotations"])
+        last["radius"] = pkgs[0]["radius"]
+        outs, ups = [], []
+        for pk in pkgs:
+            outs += [pk["render_color"], pk["allmap"]]
+            ups += [dcolor, dallmap]
+        return outs, ups
+
+    # gradients are produced directly in the all-reduce bucket whenever the bucket is consumed (N > 1, fused Adam)
+    ba = ba_shard.KeyframeShardedBA(params, render_fn, direct_grads=(_dist_on(world) or args.adam == "fused"), streams=args.streams,
+                                    batch_fn=None if (args.no_batch or args.streams > 1) else render_batch_fn)
     keyframes = list(range(world * kpg))  # keyframe i goes to rank i % world
     opt = None
     # lr = 0: the full moment update runs, the scene (and so num_rendered) stays fixed (eps as scene/Gaussians.py:137)
@@ -411,7 +436,8 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"synthetic {W}x{H} / {P} Gaussians ({args.workload}; BASELINE.md section 2), {regime} regime, "
-                               f"use_sa={use_sa}, {kpg} keyframe{'s' if kpg > 1 else ''} per GPU" + (f" on {args.streams} HIP streams" if kpg > 1 and args.streams > 1 else ""), "num_rendered": R, "num_rendered_reference_rects": R_ref, "visible": visible,
+                               f"use_sa={use_sa}, {kpg} keyframe{'s' if kpg > 1 else ''} per GPU" + (f" on {args.streams} HIP streams" if kpg > 1 and args.streams > 1 else "")
+                               + (" in one batched operator call" if kpg > 1 and ba.batch_fn is not None else ""), "num_rendered": R, "num_rendered_reference_rects": R_ref, "visible": visible,
                    "step": "op forward+backward" + (" + all-reduce of the [P,13] grad bucket" if _dist_on(world) else "")
                            + (f" + {args.adam} Adam (lr=0)" if args.adam else ""),
                    "parallelism": f"keyframe-sharded x{world}", "prewarm_steps": PREWARM_DONE,

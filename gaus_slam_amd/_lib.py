@@ -11,7 +11,28 @@ EXPORTS = ["gs2d_forward", "gs2d_backward", "gs2d_forward_posed", "gs2d_backward
            "gs2d_image_bytes", "gs2d_binning_bytes", "gs2d_geometry_layout", "gs2d_binning_layout",
            "gs2d_image_layout", "gs2d_last_error", "gs2d_build_info", "gs2d_stage_timing_enable",
            "gs2d_stage_timing_read", "gs2d_slam_loss", "gs2d_adam_step", "gs2d_pose_quat", "gs2d_backward_staged", "gs2d_set_deterministic",
-           "gs2d_get_deterministic", "gs2d_set_reference_binning", "gs2d_get_reference_binning"]
+           "gs2d_get_deterministic", "gs2d_set_reference_binning", "gs2d_get_reference_binning", "gs2d_forward_batch",
+           "gs2d_backward_batch"]
+MAX_FRAMES = 8  # GS2D_MAX_FRAMES
+
+
+class FrameIO(C.Structure):
+    """gs2d_frame_io (include/gs2d_rasterizer.h)."""
+    _fields_ = [("geometry_alloc", ALLOC_FN), ("geometry_user", C.c_void_p), ("binning_alloc", ALLOC_FN),
+                ("binning_user", C.c_void_p), ("image_alloc", ALLOC_FN), ("image_user", C.c_void_p),
+                ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("cam_pos", C.c_void_p),
+                ("out_color", C.c_void_p), ("out_others", C.c_void_p), ("radii", C.c_void_p)]
+
+
+class FrameGrad(C.Structure):
+    """gs2d_frame_grad (include/gs2d_rasterizer.h)."""
+    _fields_ = [("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("tan_fovx", C.c_float),
+                ("tan_fovy", C.c_float), ("radii", C.c_void_p), ("geom_buffer", C.c_void_p), ("binning_buffer", C.c_void_p),
+                ("img_buffer", C.c_void_p), ("num_rendered", C.c_int), ("dL_dpix", C.c_void_p), ("dL_depths", C.c_void_p),
+                ("dL_dmean2D", C.c_void_p), ("dL_dnormal", C.c_void_p), ("dL_dopacity", C.c_void_p), ("dL_dcolor", C.c_void_p),
+                ("dL_dmean3D", C.c_void_p), ("dL_dtransMat", C.c_void_p), ("dL_dsh", C.c_void_p), ("dL_dscale", C.c_void_p),
+                ("dL_drot", C.c_void_p)]
+
 
 _lib = None
 
@@ -42,6 +63,11 @@ def lib():
     L.gs2d_backward_posed.argtypes = L.gs2d_backward.argtypes[:-1] + [vp, vp, vp, vp]
     L.gs2d_backward_staged.restype = i
     L.gs2d_backward_staged.argtypes = [i, i, i] + L.gs2d_backward_posed.argtypes
+    L.gs2d_forward_batch.restype = i
+    L.gs2d_forward_batch.argtypes = [i, C.POINTER(FrameIO), i, i, i, vp, i, i, vp, vp, vp, vp, vp, f, vp, vp, i, i,
+                                     C.POINTER(C.c_int), vp]
+    L.gs2d_backward_batch.restype = i
+    L.gs2d_backward_batch.argtypes = [i, C.POINTER(FrameGrad), i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, i, i, vp]
     L.gs2d_pose_quat.restype = i
     L.gs2d_pose_quat.argtypes = [vp, vp, vp]
     L.gs2d_mark_visible.restype = i

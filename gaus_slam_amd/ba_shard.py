@@ -83,6 +83,9 @@ class GradBucket:
         return self.flat
 
 
+MAX_BATCH_KEYFRAMES = 8  # GS2D_MAX_FRAMES
+
+
 def shard_keyframes(keyframes, rank, world_size):
     """Keyframe k of the batch goes to rank k % world_size (independent units, no data-path exchange)."""
     return [kf for i, kf in enumerate(keyframes) if i % world_size == rank]
@@ -93,7 +96,8 @@ class KeyframeShardedBA:
     render_loss_fn(params, keyframe) -> scalar loss OR (outputs, upstream_grads) pair for torch.autograd.backward.
     """
 
-    def __init__(self, params, render_loss_fn, group=None, average=False, direct_grads=False, streams=1, overlap_chunks=1):
+    def __init__(self, params, render_loss_fn, group=None, average=False, direct_grads=False, streams=1, overlap_chunks=1,
+                 batch_fn=None):
         """direct_grads: let the rasterizer's backward write the parameter gradients straight into the bucket (no pack
         copies).  Safe in every case -- a gradient that did not land in the bucket (the op was not fed the leaf itself,
         e.g. activations in between) is packed by copy as before.
@@ -103,6 +107,11 @@ class KeyframeShardedBA:
         costs ~40 us of a step (one more kernel of the per-Gaussian stage, a stream hand-over to and from RCCL's stream, five
         more collectives) and can hide at most that stage's 26 us, so chunking only pays on a slow interconnect: autotune()
         decides by measurement."""
+        # batch_fn(params, [keyframes]) (optional): renders ALL the keyframes a rank holds in one batched operator call
+        # (render.render_batch / GaussianRasterizerBatch: one blend grid over the tiles of all frames) and returns a scalar
+        # loss or an (outputs, upstream_grads) pair like render_loss_fn; used whenever the rank holds 2..8 keyframes.  Same
+        # gradients as keyframe-by-keyframe rendering (per-frame results are bit-identical, sums taken in the same order).
+        self.batch_fn = batch_fn
         self.direct_grads = direct_grads
         self.overlap_chunks = max(1, int(overlap_chunks))
         self._overlap_ok = False  # set once a chunked reduction has completed
@@ -129,10 +138,10 @@ class KeyframeShardedBA:
     def rank(self):
         return dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
 
-    def local_backward(self, keyframe, sink=None, chunk_rows=None, on_chunk=None):
+    def local_backward(self, keyframe, sink=None, chunk_rows=None, on_chunk=None, fn=None):
         for p in self.params.values():
             p.grad = None
-        res = self.fn(self.params, keyframe)
+        res = (fn or self.fn)(self.params, keyframe)
         ctx = contextlib.nullcontext()
         if sink is not None:
             from . import rasterizer
@@ -299,6 +308,9 @@ class KeyframeShardedBA:
                 return self._step_overlapped(mine[0], P)
         if not mine:
             self.bucket.flat.zero_()
+        elif self.batch_fn is not None and 1 < len(mine) <= MAX_BATCH_KEYFRAMES and self.params["means3D"].is_cuda:
+            # one batched operator call for all of this rank's keyframes; frame 0's gradients land in the bucket itself
+            self.bucket.pack(self.local_backward(mine, self.bucket.views if self.direct_grads else None, fn=self.batch_fn))
         elif len(mine) > 1 and self.n_streams > 1 and self.params["means3D"].is_cuda:
             per_kf = self._multi_stream_grads(mine)
             self.bucket.pack(per_kf[0])

@@ -141,7 +141,7 @@ FwdTable g_fwd;
 // previous forward's num_rendered for the same problem shape: sizes the early binning allocation (a guess only: the
 // chunk is re-requested with the exact size when the guess was too small)
 struct LastCount { int P = -1, W = 0, H = 0; uint32_t R = 0; };
-thread_local LastCount g_last;
+thread_local LastCount g_last[GS2D_MAX_BATCH];
 
 inline void cpu_relax()
 {
@@ -208,73 +208,119 @@ void gs2d_image_layout(int width, int height, size_t o[2])
     o[0] = L.ranges; o[1] = L.pix;
 }
 
-int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_alloc_fn binning_alloc, void* binning_user,
-                       gs2d_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
-                       int height, const float* means3D, const float* shs, const float* colors_precomp,
-                       const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                       const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
-                       const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
-                       float* out_others, int* radii, int use_sa, int debug, const float* pose_Rt, const float* pose_quat,
-                       void* stream)
+}  // extern "C"
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------------------------------
+// The forward in three phases, so that K frames over the same Gaussians can share ONE blend launch (gs2d_forward_batch):
+//   A  per frame: geometry chunk, preprocess, block-sum scan (its total goes to pinned word `slot`)
+//   B  per frame: image + binning chunks, wait for the frame's num_rendered, duplicate, sort
+//   C  once:      blend_fwd over the tiles of all frames, forward records
+// gs2d_forward[_posed] is A, B, C with K = 1.
+struct FwdShared {   // what all frames of a call have in common
+    int P, D, M, width, height, use_sa, debug;
+    const float* background;
+    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *transMat_precomp;
+    float scale_modifier;
+    hipStream_t s;
+};
+struct FwdFrame {    // one frame: inputs, then the state the phases hand on
+    gs2d_alloc_fn geometry_alloc, binning_alloc, image_alloc;
+    void *geometry_user, *binning_user, *image_user;
+    const float *viewmatrix, *projmatrix, *cam_pos, *pose_Rt, *pose_quat;
+    float* out_color; float* out_others; int* radii;
+    // state
+    char* geom = nullptr; char* bin = nullptr; char* img = nullptr;
+    size_t bin_bytes = 0;
+    GeomLayout GL; CamParams cam;
+    volatile uint32_t* pinned = nullptr;
+    bool store_pending = false;  // the scan kernel WILL store into `pinned`: every return path first waits for that store
+    int R = 0;
+    gs2d::BlendFwdFrame bf;
+};
+
+int fwd_validate(const FwdShared& c)
 {
-    if ((pose_Rt == nullptr) != (pose_quat == nullptr)) return fail_msg("pose_Rt and pose_quat must be given together");
-    if (pose_Rt != nullptr && transMat_precomp != nullptr) return fail_msg("a pose cannot be combined with transMat_precomp");
-    (void)tan_fovx; (void)tan_fovy; (void)prefiltered;  // unused by the reference forward kernels as well (forward.cu:165)
-    hipStream_t s = (hipStream_t)stream;
-    if (P < 0 || width <= 0 || height <= 0) return fail_msg("bad sizes");
-    if (P == 0) return 0;  // rasterize_points.cu:100-101: zero images, rendered = 0 (outputs pre-zeroed by the caller)
-    if (!geometry_alloc || !binning_alloc || !image_alloc) return fail_msg("allocator callbacks are required");
-    if (colors_precomp == nullptr && shs == nullptr) return fail_msg("provide shs or colors_precomp");
-    if (transMat_precomp == nullptr && (scales == nullptr || rotations == nullptr))
+    if (c.P < 0 || c.width <= 0 || c.height <= 0) return fail_msg("bad sizes");
+    if (c.P == 0) return 0;
+    if (c.colors_precomp == nullptr && c.shs == nullptr) return fail_msg("provide shs or colors_precomp");
+    if (c.transMat_precomp == nullptr && (c.scales == nullptr || c.rotations == nullptr))
         return fail_msg("provide scales+rotations or transMat_precomp");
-    if (colors_precomp == nullptr && (M <= 0 || (D + 1) * (D + 1) > M)) return fail_msg("sh degree exceeds coefficients");
+    if (c.colors_precomp == nullptr && (c.M <= 0 || (c.D + 1) * (c.D + 1) > c.M)) return fail_msg("sh degree exceeds coefficients");
+    return 0;
+}
 
-    // hipGetLastError is per host thread and keeps the last failure until it is read: drop whatever another library (or an
-    // earlier, already reported call) left behind, so that the checks below only ever see this call's launches.  A device
-    // that is truly lost fails the next launch again.
-    (void)hipGetLastError();
-    const GeomLayout GL = geom_layout(P);
-    char* geom = (char*)geometry_alloc(geometry_user, GL.total);
-    if (!geom) return fail_msg("geometry allocation failed");
-    g_fwd.drop(geom);
-    const ImgLayout IL = img_layout(width, height);
+// Poll, then yield: the store normally lands within tens of microseconds (preprocess + block-sum scan), so the thread spins
+// with `pause` for at most ~100 us; if the stream is backed up behind earlier work (or several ranks share the host's cores)
+// it hands its time slice back between looks instead of burning a core per rank.  Falls back to a real synchronise after
+// ~2 s (surfacing any GPU error).
+bool wait_total(FwdFrame& f, hipStream_t s)
+{
+    if (!f.store_pending) return true;
+    f.store_pending = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t spins = 0;
+    bool yielding = false;
+    while (*f.pinned == 0xFFFFFFFFu) {
+        if (yielding) std::this_thread::yield(); else cpu_relax();
+        if ((++spins & (yielding ? 0x3Fu : 0x3FFu)) == 0) {
+            const auto dt = std::chrono::steady_clock::now() - t0;
+            if (dt > std::chrono::seconds(2)) return hipStreamSynchronize(s) == hipSuccess && *f.pinned != 0xFFFFFFFFu;
+            if (dt > std::chrono::microseconds(100)) yielding = true;
+        }
+    }
+    return true;
+}
 
-    CamParams cam;
-    cam.vm = viewmatrix; cam.pm = projmatrix; cam.campos = cam_pos;
-    cam.W = width; cam.H = height;
-    cam.gx = (width + GS2D_TILE - 1) / GS2D_TILE;
-    cam.gy = (height + GS2D_TILE - 1) / GS2D_TILE;
+int fwd_phase_a(const FwdShared& c, FwdFrame& f, int slot)
+{
+    const int debug = c.debug;
+    hipStream_t s = c.s;
+    if ((f.pose_Rt == nullptr) != (f.pose_quat == nullptr)) return fail_msg("pose_Rt and pose_quat must be given together");
+    if (f.pose_Rt != nullptr && c.transMat_precomp != nullptr) return fail_msg("a pose cannot be combined with transMat_precomp");
+    if (!f.geometry_alloc || !f.binning_alloc || !f.image_alloc) return fail_msg("allocator callbacks are required");
+    f.GL = geom_layout(c.P);
+    const GeomLayout& GL = f.GL;
+    f.geom = (char*)f.geometry_alloc(f.geometry_user, GL.total);
+    if (!f.geom) return fail_msg("geometry allocation failed");
+    g_fwd.drop(f.geom);
+
+    CamParams& cam = f.cam;
+    cam.vm = f.viewmatrix; cam.pm = f.projmatrix; cam.campos = f.cam_pos;
+    cam.W = c.width; cam.H = c.height;
+    cam.gx = (c.width + GS2D_TILE - 1) / GS2D_TILE;
+    cam.gy = (c.height + GS2D_TILE - 1) / GS2D_TILE;
     cam.tight = g_reference_binning.load() == 0;
 
+    char* geom = f.geom;
     float* depths = (float*)(geom + GL.depths);
     uint32_t* tiles_touched = (uint32_t*)(geom + GL.tiles_touched);
-    uint32_t* point_offsets = (uint32_t*)(geom + GL.point_offsets);
     float4* rec = (float4*)(geom + GL.rec);
     uint8_t* clamped = (uint8_t*)(geom + GL.clamped);
     ushort4* rect = (ushort4*)(geom + GL.rect);
     uint32_t* scan_tmp = (uint32_t*)(geom + GL.scan_tmp);
 
     g_timer.begin(ST_PREPROCESS, s);
-    gs2d::launch_preprocess_fwd(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, transMat_precomp,
-                                colors_precomp, cam, radii, depths, rec, tiles_touched, rect, clamped, pose_Rt, pose_quat, scan_tmp,
-                                s);
+    gs2d::launch_preprocess_fwd(c.P, c.D, c.M, c.means3D, c.scales, c.scale_modifier, c.rotations, c.opacities, c.shs,
+                                c.transMat_precomp, c.colors_precomp, cam, f.radii, depths, rec, tiles_touched, rect, clamped,
+                                f.pose_Rt, f.pose_quat, scan_tmp, s);
     g_timer.end(ST_PREPROCESS, s);
     GS2D_STAGE("preprocess");
 
-    const int nblk = (P + 255) / 256;  // scan_tmp[0..nblk) = per-workgroup sums, then exclusive block offsets
+    const int nblk = (c.P + 255) / 256;  // scan_tmp[0..nblk) = per-workgroup sums, then exclusive block offsets
     uint32_t* total_dev = scan_tmp + nblk + 8;
     // The one host sync of the forward (rasterizer_impl.cu:287): the binning chunk is sized by num_rendered.
     // Read-back without an OS-level wait and without a copy: the scan stores the total straight into a pinned host word
-    // (system-scope store, issued as soon as the total is known) that was pre-set to a sentinel and is polled below.
+    // (system-scope store, issued as soon as the total is known) that was pre-set to a sentinel and is polled in phase B.
     // On a loaded host a blocking hipStreamSynchronize can cost milliseconds of scheduler latency per call; the poll
-    // returns within a microsecond of the store landing.  Falls back to a real synchronise after ~2 s (surfacing any
-    // GPU error).
+    // returns within a microsecond of the store landing.
     // coherent pinned memory: the device's system-scope store must become visible to the polling CPU without a sync
     if (!g_pinned.p) GS2D_CHECK(hipHostMalloc((void**)&g_pinned.p, 64, hipHostMallocCoherent), "hipHostMalloc");
-    volatile uint32_t* pinned = g_pinned.p;
-    *pinned = 0xFFFFFFFFu;
+    f.pinned = g_pinned.p + slot;  // 16 words: one per frame of a batch
+    *f.pinned = 0xFFFFFFFFu;
     g_timer.begin(ST_SCAN, s);
-    gs2d::launch_offsets_blocksums(P, scan_tmp, total_dev, g_pinned.p, s);
+    gs2d::launch_offsets_blocksums(c.P, scan_tmp, total_dev, g_pinned.p + slot, s);
     g_timer.end(ST_SCAN, s);
     {
         const hipError_t le = hipGetLastError();
@@ -282,56 +328,58 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     }
     // From here on the scan kernel WILL store into the pinned word, so every return path first waits for that store
     // (a later forward on this thread would otherwise reset the sentinel and could pick up this call's stale total).
-    // Poll, then yield: the store normally lands within tens of microseconds (preprocess + block-sum scan), so the thread
-    // spins with `pause` for at most ~100 us; if the stream is backed up behind earlier work (or several ranks share the
-    // host's cores) it hands its time slice back between looks instead of burning a core per rank.
-    auto wait_total = [&]() -> bool {
-        const auto t0 = std::chrono::steady_clock::now();
-        uint64_t spins = 0;
-        bool yielding = false;
-        while (*pinned == 0xFFFFFFFFu) {
-            if (yielding) std::this_thread::yield(); else cpu_relax();
-            if ((++spins & (yielding ? 0x3Fu : 0x3FFu)) == 0) {
-                const auto dt = std::chrono::steady_clock::now() - t0;
-                if (dt > std::chrono::seconds(2)) return hipStreamSynchronize(s) == hipSuccess && *pinned != 0xFFFFFFFFu;
-                if (dt > std::chrono::microseconds(100)) yielding = true;
-            }
-        }
-        return true;
-    };
+    f.store_pending = true;
+    return 0;
+}
+
+int fwd_phase_b(const FwdShared& c, FwdFrame& f, int slot)
+{
+    const int debug = c.debug;
+    hipStream_t s = c.s;
+    const int P = c.P, width = c.width, height = c.height;
+    const GeomLayout& GL = f.GL;
+    const CamParams& cam = f.cam;
+    const ImgLayout IL = img_layout(width, height);
     // While the GPU works towards num_rendered, ask for the image chunk and already for the binning chunk, sized from the
     // previous call's count for this problem shape (+12.5 %): the allocator callbacks (trips through the caller's runtime)
     // then cost nothing on the critical path.  If the guess turns out too small the callback is simply invoked a second
     // time with the exact size.
-    char* img = (char*)image_alloc(image_user, IL.total);
-    if (!img) { (void)wait_total(); return fail_msg("image allocation failed"); }
-    const bool same_shape = g_last.P == P && g_last.W == width && g_last.H == height;
-    const size_t guess_R = same_shape ? (size_t)g_last.R + g_last.R / 8 + 4096 : (size_t)P * 3 + 4096;
+    f.img = (char*)f.image_alloc(f.image_user, IL.total);
+    if (!f.img) { (void)wait_total(f, s); return fail_msg("image allocation failed"); }
+    LastCount& last = g_last[slot];
+    const bool same_shape = last.P == P && last.W == width && last.H == height;
+    const size_t guess_R = same_shape ? (size_t)last.R + last.R / 8 + 4096 : (size_t)P * 3 + 4096;
     const bool det = g_deterministic.load() != 0;
     const size_t pre_bytes = bin_layout((int)(guess_R > 0x7fffffffull ? 0x7fffffffull : guess_R), det).total;
-    char* bin_pre = (char*)binning_alloc(binning_user, pre_bytes);
-    if (!wait_total()) return fail_msg("num_rendered read-back failed");
+    char* bin_pre = (char*)f.binning_alloc(f.binning_user, pre_bytes);
+    if (!wait_total(f, s)) return fail_msg("num_rendered read-back failed");
     if (debug) GS2D_CHECK(hipStreamSynchronize(s), "scan");
-    const uint32_t num_rendered_u = *pinned;
+    const uint32_t num_rendered_u = *f.pinned;
     if (num_rendered_u == 0xFFFFFFFFu) return fail_msg("num_rendered read-back failed");
     if (num_rendered_u > 0x7fffffffu) return fail_msg("num_rendered overflows int32");
     const int R = (int)num_rendered_u;
+    f.R = R;
 
-    g_last.P = P; g_last.W = width; g_last.H = height; g_last.R = num_rendered_u;
+    last.P = P; last.W = width; last.H = height; last.R = num_rendered_u;
     const BinLayout BL = bin_layout(R, det);  // offsets always follow the true count; the chunk may be larger than BL.total
     const bool reuse_pre = bin_pre && BL.total <= pre_bytes;
-    char* bin = reuse_pre ? bin_pre : (char*)binning_alloc(binning_user, BL.total);
+    char* bin = reuse_pre ? bin_pre : (char*)f.binning_alloc(f.binning_user, BL.total);
     if (!bin) return fail_msg("binning allocation failed");
-    const size_t bin_bytes = reuse_pre ? pre_bytes : BL.total;
+    f.bin = bin;
+    f.bin_bytes = reuse_pre ? pre_bytes : BL.total;
+    char* geom = f.geom;
+    char* img = f.img;
+    float* depths = (float*)(geom + GL.depths);
+    uint32_t* tiles_touched = (uint32_t*)(geom + GL.tiles_touched);
+    uint32_t* point_offsets = (uint32_t*)(geom + GL.point_offsets);
+    ushort4* rect = (ushort4*)(geom + GL.rect);
+    uint32_t* scan_tmp = (uint32_t*)(geom + GL.scan_tmp);
     uint32_t* point_list = (uint32_t*)(bin + BL.point_list);
-    uint8_t* hits = (uint8_t*)(bin + BL.hits);
-    uint8_t* hits4 = (uint8_t*)(bin + BL.hits4);
     uint64_t* keys = (uint64_t*)(bin + BL.keys);
     uint32_t* vals_alt = (uint32_t*)(bin + BL.vals_alt);
     uint64_t* keys_alt = (uint64_t*)(bin + BL.keys_alt);
     uint32_t* hist = (uint32_t*)(bin + BL.hist);
     uint2* ranges = (uint2*)(img + IL.ranges);
-    float* pix_state = (float*)(img + IL.pix);
 
     // Sort = (a) stable binning of the pairs by tile id (single counting-sort pass; 8-bit radix passes on the tile
     // bits when there are too many tiles for LDS), Gaussian order kept inside a tile; (b) tile ranges; (c) per-tile
@@ -369,17 +417,106 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
         g_timer.end(ST_SORT, s);
         GS2D_STAGE("tile depth sort");
     }
+    f.bf.ranges = ranges; f.bf.point_list = point_list; f.bf.rec = (const float4*)(geom + GL.rec);
+    f.bf.out_color = f.out_color; f.bf.out_others = f.out_others; f.bf.pix_state = (float*)(img + IL.pix);
+    f.bf.hits = (uint8_t*)(bin + BL.hits); f.bf.hits4 = (uint8_t*)(bin + BL.hits4);
+    f.bf.zero = (float4*)(geom + GL.grad_rec);
+    return 0;
+}
+
+int fwd_phase_c(const FwdShared& c, FwdFrame* frames, int K)
+{
+    const int debug = c.debug;
+    hipStream_t s = c.s;
+    gs2d::BlendFwdFrame bf[GS2D_MAX_BATCH];
+    for (int k = 0; k < K; k++) bf[k] = frames[k].bf;
     g_timer.begin(ST_BLEND_FWD, s);
-    gs2d::launch_blend_fwd(width, height, ranges, point_list, rec, background, out_color, out_others, pix_state, hits, hits4,
-                           use_sa, (float4*)(geom + GL.grad_rec), (size_t)P * (GS2D_GRAD_FLOATS / 4), s);
-    {
+    gs2d::launch_blend_fwd(c.width, c.height, K, bf, c.background, c.use_sa, (size_t)c.P * (GS2D_GRAD_FLOATS / 4), s);
+    const bool det = g_deterministic.load() != 0;
+    for (int k = 0; k < K; k++) {
         FwdRecord fr;
-        fr.geom = geom; fr.bin = bin; fr.bin_bytes = bin_bytes; fr.det = det ? 1 : 0; fr.R = R; fr.P = P; fr.clean = true;
+        fr.geom = frames[k].geom; fr.bin = frames[k].bin; fr.bin_bytes = frames[k].bin_bytes; fr.det = det ? 1 : 0;
+        fr.R = frames[k].R; fr.P = c.P; fr.clean = true;
         g_fwd.add(fr);
     }
     g_timer.end(ST_BLEND_FWD, s);
     GS2D_STAGE("blend_fwd");
-    return R;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_alloc_fn binning_alloc, void* binning_user,
+                       gs2d_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                       int height, const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                       const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
+                       const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                       float* out_others, int* radii, int use_sa, int debug, const float* pose_Rt, const float* pose_quat,
+                       void* stream)
+{
+    (void)tan_fovx; (void)tan_fovy; (void)prefiltered;  // unused by the reference forward kernels as well (forward.cu:165)
+    FwdShared c;
+    c.P = P; c.D = D; c.M = M; c.width = width; c.height = height; c.use_sa = use_sa; c.debug = debug;
+    c.background = background; c.means3D = means3D; c.shs = shs; c.colors_precomp = colors_precomp; c.opacities = opacities;
+    c.scales = scales; c.rotations = rotations; c.transMat_precomp = transMat_precomp; c.scale_modifier = scale_modifier;
+    c.s = (hipStream_t)stream;
+    if ((pose_Rt == nullptr) != (pose_quat == nullptr)) return fail_msg("pose_Rt and pose_quat must be given together");
+    if (pose_Rt != nullptr && transMat_precomp != nullptr) return fail_msg("a pose cannot be combined with transMat_precomp");
+    if (fwd_validate(c) < 0) return -1;
+    if (P == 0) return 0;  // rasterize_points.cu:100-101: zero images, rendered = 0 (outputs pre-zeroed by the caller)
+    // hipGetLastError is per host thread and keeps the last failure until it is read: drop whatever another library (or an
+    // earlier, already reported call) left behind, so that the checks below only ever see this call's launches.  A device
+    // that is truly lost fails the next launch again.
+    (void)hipGetLastError();
+    FwdFrame f;
+    f.geometry_alloc = geometry_alloc; f.geometry_user = geometry_user; f.binning_alloc = binning_alloc;
+    f.binning_user = binning_user; f.image_alloc = image_alloc; f.image_user = image_user;
+    f.viewmatrix = viewmatrix; f.projmatrix = projmatrix; f.cam_pos = cam_pos; f.pose_Rt = pose_Rt; f.pose_quat = pose_quat;
+    f.out_color = out_color; f.out_others = out_others; f.radii = radii;
+    if (fwd_phase_a(c, f, 0) < 0) { (void)wait_total(f, c.s); return -1; }
+    if (fwd_phase_b(c, f, 0) < 0) { (void)wait_total(f, c.s); return -1; }
+    if (fwd_phase_c(c, &f, 1) < 0) return -1;
+    return f.R;
+}
+
+int gs2d_forward_batch(int K, const gs2d_frame_io* io, int P, int D, int M, const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                       const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
+                       int use_sa, int debug, int* num_rendered, void* stream)
+{
+    if (K < 1 || K > GS2D_MAX_BATCH) return fail_msg("K must be between 1 and GS2D_MAX_FRAMES (8)");
+    if (!io || !num_rendered) return fail_msg("null pointer");
+    FwdShared c;
+    c.P = P; c.D = D; c.M = M; c.width = width; c.height = height; c.use_sa = use_sa; c.debug = debug;
+    c.background = background; c.means3D = means3D; c.shs = shs; c.colors_precomp = colors_precomp; c.opacities = opacities;
+    c.scales = scales; c.rotations = rotations; c.transMat_precomp = transMat_precomp; c.scale_modifier = scale_modifier;
+    c.s = (hipStream_t)stream;
+    if (fwd_validate(c) < 0) return -1;
+    for (int k = 0; k < K; k++) num_rendered[k] = 0;
+    if (P == 0) return 0;
+    (void)hipGetLastError();
+    FwdFrame f[GS2D_MAX_BATCH];
+    for (int k = 0; k < K; k++) {
+        f[k].geometry_alloc = io[k].geometry_alloc; f[k].geometry_user = io[k].geometry_user;
+        f[k].binning_alloc = io[k].binning_alloc; f[k].binning_user = io[k].binning_user;
+        f[k].image_alloc = io[k].image_alloc; f[k].image_user = io[k].image_user;
+        f[k].viewmatrix = io[k].viewmatrix; f[k].projmatrix = io[k].projmatrix; f[k].cam_pos = io[k].cam_pos;
+        f[k].pose_Rt = nullptr; f[k].pose_quat = nullptr;
+        f[k].out_color = io[k].out_color; f[k].out_others = io[k].out_others; f[k].radii = io[k].radii;
+    }
+    auto drain = [&]() { for (int k = 0; k < K; k++) (void)wait_total(f[k], c.s); };
+    // all K preprocess + scan pairs are enqueued before the host looks at the first total: by the time frame 0's chunks
+    // have been requested, the later frames' totals are already on their way
+    for (int k = 0; k < K; k++)
+        if (fwd_phase_a(c, f[k], k) < 0) { drain(); return -1; }
+    for (int k = 0; k < K; k++)
+        if (fwd_phase_b(c, f[k], k) < 0) { drain(); return -1; }
+    if (fwd_phase_c(c, f, K) < 0) return -1;
+    for (int k = 0; k < K; k++) num_rendered[k] = f[k].R;
+    return 0;
 }
 
 int gs2d_forward(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_alloc_fn binning_alloc, void* binning_user,
@@ -467,8 +604,8 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
             GS2D_CHECK(hipMemsetAsync(grad_rec, 0, sizeof(float) * GS2D_GRAD_FLOATS * (size_t)P, s), "memset grad_rec");
         if (R > 0) {
             g_timer.begin(ST_BLEND_BWD, s);
-            gs2d::launch_blend_bwd(width, height, ranges, point_list, rec, background, pix_state, hits, dL_dpix, dL_depths,
-                                   grad_rec, use_sa, nullptr, dL_dpose, pose_floats, s);
+            const gs2d::BlendBwdFrame bf = {ranges, point_list, rec, pix_state, hits, dL_dpix, dL_depths, grad_rec, nullptr};
+            gs2d::launch_blend_bwd(width, height, 1, &bf, background, use_sa, dL_dpose, pose_floats, s);
             g_timer.end(ST_BLEND_BWD, s);
             GS2D_STAGE("blend_bwd");
         }
@@ -481,8 +618,8 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         g_timer.begin(ST_BLEND_BWD, s);
         if (R > 0) {
             GS2D_CHECK(hipMemsetAsync(det_slots, 0, sizeof(float) * GS2D_GRAD_FLOATS * 4 * (size_t)R, s), "memset det_slots");
-            gs2d::launch_blend_bwd(width, height, ranges, point_list, rec, background, pix_state, hits, dL_dpix, dL_depths,
-                                   grad_rec, use_sa, det_slots, nullptr, 0, s);
+            const gs2d::BlendBwdFrame bf = {ranges, point_list, rec, pix_state, hits, dL_dpix, dL_depths, grad_rec, det_slots};
+            gs2d::launch_blend_bwd(width, height, 1, &bf, background, use_sa, nullptr, 0, s);
         }
         gs2d::launch_det_reduce(P, R, width, height, ranges, point_list, (const ushort4*)(geom_buffer + GL.rect),
                                 (const uint32_t*)(geom_buffer + GL.tiles_touched),
@@ -511,6 +648,67 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
                                     (live_det && pose_Rt) ? (float*)(geom_buffer + GL.depths) : nullptr, s);
         g_timer.end(ST_PREPROCESS_BWD, s);
         GS2D_STAGE("preprocess_bwd");
+    }
+    return 0;
+}
+
+int gs2d_backward_batch(int K, const gs2d_frame_grad* fr, int P, int D, int M, const float* background, int width, int height,
+                        const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                        float scale_modifier, const float* rotations, const float* transMat_precomp, int use_sa, int debug,
+                        void* stream)
+{
+    if (K < 1 || K > GS2D_MAX_BATCH) return fail_msg("K must be between 1 and GS2D_MAX_FRAMES (8)");
+    if (!fr) return fail_msg("null pointer");
+    if (g_deterministic.load() != 0) return fail_msg("the batched backward has no deterministic variant: call gs2d_backward per frame");
+    if (P <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const GeomLayout GL = geom_layout(P);
+    const ImgLayout IL = img_layout(width, height);
+    gs2d::BlendBwdFrame bf[GS2D_MAX_BATCH];
+    int nb = 0;  // frames with instances: only those take part in the blend launch
+    for (int k = 0; k < K; k++) {
+        const gs2d_frame_grad& f = fr[k];
+        const int R = f.num_rendered;
+        if (!f.geom_buffer || !f.img_buffer || (R > 0 && !f.binning_buffer)) return fail_msg("missing forward state");
+        FwdRecord rec;
+        const bool known = g_fwd.find(f.geom_buffer, /*take_clean=*/true, &rec);
+        if (known) {
+            if (rec.P != P) return fail_msg("P is not the Gaussian count of the forward that produced this geometry chunk");
+            if (rec.R != R) return fail_msg("R is not the num_rendered of the forward that produced this geometry chunk");
+            if (R > 0 && rec.bin != (const void*)f.binning_buffer)
+                return fail_msg("binning_buffer is not the chunk the forward of this geometry chunk was given");
+            if (rec.det != 0) return fail_msg("gs2d_set_deterministic changed between this forward and its backward");
+        }
+        float* grad_rec = (float*)(f.geom_buffer + GL.grad_rec);
+        if (!(known && rec.clean))
+            GS2D_CHECK(hipMemsetAsync(grad_rec, 0, sizeof(float) * GS2D_GRAD_FLOATS * (size_t)P, s), "memset grad_rec");
+        if (R > 0) {
+            const BinLayout BL = bin_layout(R, false);
+            if (known && BL.total > rec.bin_bytes) return fail_msg("binning chunk is smaller than the layout of this backward");
+            gs2d::BlendBwdFrame& b = bf[nb++];
+            b.ranges = (const uint2*)(f.img_buffer + IL.ranges);
+            b.point_list = (const uint32_t*)(f.binning_buffer + BL.point_list);
+            b.rec = (const float4*)(f.geom_buffer + GL.rec);
+            b.pix_state = (const float*)(f.img_buffer + IL.pix);
+            b.hits = (const uint8_t*)(f.binning_buffer + BL.hits4);
+            b.dL_dpix = f.dL_dpix; b.dL_dothers = f.dL_depths; b.grad_rec = grad_rec; b.det_slots = nullptr;
+        }
+    }
+    if (nb > 0) {
+        g_timer.begin(ST_BLEND_BWD, s);
+        gs2d::launch_blend_bwd(width, height, nb, bf, background, use_sa, nullptr, 0, s);
+        g_timer.end(ST_BLEND_BWD, s);
+        GS2D_STAGE("blend_bwd (batch)");
+    }
+    for (int k = 0; k < K; k++) {  // the per-Gaussian stage, frame by frame (each frame has its own outputs)
+        const gs2d_frame_grad& f = fr[k];
+        const int rc = gs2d_backward_staged(GS2D_BWD_PREPROCESS, 0, P, P, D, M, f.num_rendered, background, width, height, means3D, shs,
+                                            colors_precomp, scales, scale_modifier, rotations, transMat_precomp, f.viewmatrix,
+                                            f.projmatrix, f.campos, f.tan_fovx, f.tan_fovy, f.radii, f.geom_buffer, f.binning_buffer,
+                                            f.img_buffer, f.dL_dpix, f.dL_depths, f.dL_dmean2D, f.dL_dnormal, f.dL_dopacity,
+                                            f.dL_dcolor, f.dL_dmean3D, f.dL_dtransMat, f.dL_dsh, f.dL_dscale, f.dL_drot, use_sa, debug,
+                                            nullptr, nullptr, nullptr, stream);
+        if (rc < 0) return rc;
     }
     return 0;
 }

@@ -178,22 +178,42 @@ __device__ __forceinline__ int rank_below(uint64_t b)
 // Side job of the forward blend: clear the backward's gradient accumulator with this kernel's idle store path (fire-and-
 // forget stores as every wave finishes), so that the backward starts without a memset on its critical path.  Every
 // thread of the grid takes its share, the padding workgroups too.
-__device__ __forceinline__ void clear_share(float4* __restrict__ zero, size_t zero_n)
+__device__ __forceinline__ void clear_share(float4* __restrict__ zero, size_t zero_n, int block, int nblocks)
 {
-    for (size_t z = (size_t)blockIdx.x * 256 + threadIdx.x; z < zero_n; z += (size_t)gridDim.x * 256)
+    for (size_t z = (size_t)block * 256 + threadIdx.x; z < zero_n; z += (size_t)nblocks * 256)
         zero[z] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-template <bool USE_SA>
+// BATCH: one grid over the tiles of K frames (gs2d_forward_batch): frame = blockIdx.x / blocks_per_frame, the per-frame
+// pointers come from a by-value table in the kernel arguments (one scalar load), everything else is shared.  Workgroups
+// are dispatched in blockIdx order, so the frames run one after the other and the next frame's tiles fill the SIMDs the
+// previous frame's last waves leave idle.  The single-frame instantiation is the same code with the table's first entry.
+template <bool USE_SA, bool BATCH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS2D_FWD_WAVES_PER_EU, GS2D_FWD_WAVES_PER_EU)))
-blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                 const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
-                 float* __restrict__ out_others, float* __restrict__ pix_state, size_t plane, uint8_t* hits /* written by phase 0: neither const nor restrict */, uint8_t* hits4,
-                 float4* __restrict__ zero, size_t zero_n)
+blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const float* __restrict__ bg, size_t plane, size_t zero_n,
+                 const std::conditional_t<BATCH, gs2d::BlendFwdBatch, gs2d::BlendFwdFrame> args)
 {
     __shared__ FwdBatch batches[4];
-    const int tile = xcd_tile(blockIdx.x, ntiles);
-    if (tile < 0) { clear_share(zero, zero_n); return; }
+    int local_block = blockIdx.x;
+    const gs2d::BlendFwdFrame* fa;
+    if constexpr (BATCH) {
+        const int frame = blockIdx.x / blocks_per_frame;
+        local_block = blockIdx.x - frame * blocks_per_frame;
+        fa = &args.f[frame];
+    } else {
+        fa = &args;
+    }
+    const uint2* __restrict__ ranges = fa->ranges;
+    const uint32_t* __restrict__ point_list = fa->point_list;
+    const float4* __restrict__ rec = fa->rec;
+    float* __restrict__ out_color = fa->out_color;
+    float* __restrict__ out_others = fa->out_others;
+    float* __restrict__ pix_state = fa->pix_state;
+    uint8_t* hits = fa->hits;    /* written by phase 0: neither const nor restrict */
+    uint8_t* hits4 = fa->hits4;
+    float4* __restrict__ zero = fa->zero;
+    const int tile = xcd_tile(local_block, ntiles);
+    if (tile < 0) { clear_share(zero, zero_n, local_block, blocks_per_frame); return; }
     const int tx = tile % gx, ty = tile / gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     FwdBatch& wb = batches[wave];
@@ -272,8 +292,17 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
         wave_lds_sync();
         // the sixteen group queues: slot numbers of the splats whose bit r is set, in slot (= depth) order, ended by 255
         reinterpret_cast<uint4*>(&wb.ql[0][0])[lane] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        const uint32_t nib = lane < fill ? (uint32_t)wb.tm[lane] : 0u;
-        int trips = 0;  // the longest queue; >= 1: every staged splat touches some group
+        // groups whose four pixels are all finished (saturated, or outside the image) take no more splats: their queues stay
+        // empty from this batch on, so the batch's trip count is the longest queue among the groups still at work
+        // (scripts/dev/group_trips.c: 719k -> 686k trips per frame on the bench scene, where every pixel saturates)
+        uint64_t dq = __ballot(done);
+        dq &= dq >> 1; dq &= dq >> 2; dq &= 0x1111111111111111ull;            // bit 4g: group g is finished
+        dq = (dq | (dq >> 3)) & 0x0303030303030303ull;                         // gather the sixteen bits ...
+        dq = (dq | (dq >> 6)) & 0x000F000F000F000Full;
+        dq = (dq | (dq >> 12)) & 0x000000FF000000FFull;
+        const uint32_t done16 = (uint32_t)(dq | (dq >> 24)) & 0xFFFFu;         // ... bit g: group g is finished
+        const uint32_t nib = lane < fill ? (uint32_t)wb.tm[lane] & ~done16 : 0u;
+        int trips = 0;  // the longest queue (0: everything staged belongs to finished groups -- the trip loop then runs one idle step)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const bool in_r = ((nib >> r) & 1u) != 0u;
@@ -363,7 +392,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
         reinterpret_cast<uint32_t*>(pix_state)[PS_LAST * plane + si] = last_contributor;
         reinterpret_cast<uint32_t*>(pix_state)[PS_MEDC * plane + si] = median_contributor;
     }
-    clear_share(zero, zero_n);
+    clear_share(zero, zero_n, local_block, blocks_per_frame);
 }
 
 // The backward keeps one queue per 4x4 sub-block (16-lane DPP row): finer queues would cut its trips too, but every
@@ -454,8 +483,9 @@ __device__ __forceinline__ float reduce16_row_z(const float v[16], int lane)
         : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(e4), "=&v"(e5), "=&v"(e7)
         : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]),
           "v"(v[10]), "v"(v[11]), "v"(v[15]));
-    f3 = 0.f;
-    asm("v_add_f32_dpp %0, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+    // (f3's zero is written inside the block: as an input it would pin a register holding 0.0 through the whole trip loop)
+    asm("v_mov_b32 %3, 0\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %1, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %2, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %3, %10, %10 row_half_mirror row_mask:0xf bank_mask:0x8\n\t"  /* lanes 12-15 <- value 15 */
@@ -463,7 +493,7 @@ __device__ __forceinline__ float reduce16_row_z(const float v[16], int lane)
         "v_add_f32_dpp %1, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
         "v_add_f32_dpp %2, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
         "s_nop 1"
-        : "=&v"(f0), "=&v"(f1), "=&v"(f2), "+v"(f3)
+        : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3)
         : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(e4), "v"(e5), "v"(e7));
     const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
     const float g0 = seladd<0x4E>(f0, f1, b1), g1 = seladd<0x4E>(f2, f3, b1);
@@ -561,19 +591,35 @@ struct BwdBatchT {
     uint32_t tail[4];   // the pipeline reads up to two entries past a full queue (values unused)
 };
 
-template <bool USE_SA, bool DET>
+template <bool USE_SA, bool DET, bool BATCH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DET ? 4 : GS2D_WAVES_PER_EU, DET ? 4 : GS2D_WAVES_PER_EU)))
-blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                 const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ pix_state,
-                 size_t plane, const uint8_t* __restrict__ hits, const float* __restrict__ dL_dpix,
-                 const float* __restrict__ dL_dothers, float* __restrict__ grad_rec, float* __restrict__ det_slots,
-                 float* __restrict__ clear12, int clear_n)
+blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const float* __restrict__ bg, size_t plane,
+                 float* __restrict__ clear12, int clear_n,
+                 const std::conditional_t<BATCH, gs2d::BlendBwdBatch, gs2d::BlendBwdFrame> args)
 {
     if (clear12 != nullptr && blockIdx.x == 0 && (int)threadIdx.x < clear_n) clear12[threadIdx.x] = 0.f;
     constexpr int NACC = DET ? GS2D_ACC_DET : GS2D_ACC;
     typedef BwdBatchT<NACC> BwdBatch;
     __shared__ BwdBatch batches[4];
-    const int tile = xcd_tile(blockIdx.x, ntiles);
+    int local_block = blockIdx.x;
+    const gs2d::BlendBwdFrame* fa;
+    if constexpr (BATCH) {  // see blend_fwd_kernel
+        const int frame = blockIdx.x / blocks_per_frame;
+        local_block = blockIdx.x - frame * blocks_per_frame;
+        fa = &args.f[frame];
+    } else {
+        fa = &args;
+    }
+    const uint2* __restrict__ ranges = fa->ranges;
+    const uint32_t* __restrict__ point_list = fa->point_list;
+    const float4* __restrict__ rec = fa->rec;
+    const float* __restrict__ pix_state = fa->pix_state;
+    const uint8_t* __restrict__ hits = fa->hits;
+    const float* __restrict__ dL_dpix = fa->dL_dpix;
+    const float* __restrict__ dL_dothers = fa->dL_dothers;
+    float* __restrict__ grad_rec = fa->grad_rec;
+    float* __restrict__ det_slots = fa->det_slots;
+    const int tile = xcd_tile(local_block, ntiles);
     if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -619,17 +665,29 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
     const float final_A = 1 - T_final;
     // background term of dL_dalpha, -T_final/(1-alpha) * dot(bg, dL_dpixel) (backward.cu:407-410): the two per-pixel factors
     // are folded into one register (one rounding apart from the oracle's (-T_final * ioma) * bg_dot; exactly 0 for bg = 0)
-    const float tf_bg = T_final * fmaf(bg[2], dpx2, fmaf(bg[1], dpx1, bg[0] * dpx0));
+    // ... and so is the opacity-map term (backward.cu:386-389): the reference keeps accum_alpha_rec = 1 - prod(1 - alpha_j) over the
+    // splats behind the current one and adds (1 - accum_alpha_rec) * dL_daccum before the multiplication by T; that product is
+    // T_final / (T (1 - alpha)), so the term equals +T_final/(1-alpha) * dL_daccum -- the background term's form.  Both ride in
+    // one register: a recurrence, a per-pixel constant and three operations per trip less (rounding-level deviation from the
+    // oracle's recurrence: the closed form is the more accurate of the two where 1 - accum_alpha_rec cancels).
+    const float tf_bg = T_final * (fmaf(bg[2], dpx2, fmaf(bg[1], dpx1, bg[0] * dpx0)) - dL_daccum);
     const float sa_k = 1.0f / (4 * fmaxf(mstd * (1.0f / (1 - T_final)), 1e-7f));  // per-pixel constant (IEEE, as the oracle)
     const float c1f = GS2D_FAR_N / (GS2D_FAR_N - GS2D_NEAR_N);
     float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
-    float last_depth = 0.f, ln0 = 0.f, ln1 = 0.f, ln2 = 0.f, accum_depth_rec = 0.f, accum_alpha_rec = 0.f;
+    float last_depth = 0.f, ln0 = 0.f, ln1 = 0.f, ln2 = 0.f, accum_depth_rec = 0.f;
     float an0 = 0.f, an1 = 0.f, an2 = 0.f, last_dL_dT = 0.f, last_alpha = 0.f;
 
     // nothing behind the deepest contributor of this quadrant can receive a gradient from it
     uint32_t max_last = last_contributor;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) max_last = max(max_last, (uint32_t)__shfl_xor((int)max_last, d, 64));
+    // ... and nothing behind the deepest contributor of a 4x4 ROW can receive a gradient from that row: its queue leaves those
+    // splats out (the quadrant-level bound above only decides where the walk starts; 954k -> 933k trips per frame)
+    uint32_t row_last = last_contributor;
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) row_last = max(row_last, (uint32_t)__shfl_xor((int)row_last, d, 64));
+    const uint32_t row_last0 = (uint32_t)__builtin_amdgcn_readlane((int)row_last, 0), row_last1 = (uint32_t)__builtin_amdgcn_readlane((int)row_last, 16),
+                   row_last2 = (uint32_t)__builtin_amdgcn_readlane((int)row_last, 32), row_last3 = (uint32_t)__builtin_amdgcn_readlane((int)row_last, 48);
     max_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_last);
 
     // butterfly slot held by this lane -> offset in the gradient record, and the sign of that component.  Slots:
@@ -720,7 +778,11 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
         wave_lds_sync();
         // four depth-ordered queues, one per 4x4 sub-block (= DPP row): byte lists of slot numbers, deepest (= highest
         // slot) first, so walking a list front to back visits the row's splats back to front
-        const uint32_t nib = lane >= 64 - fill ? wb.pn[lane] : 0u;
+        uint32_t nib = lane >= 64 - fill ? wb.pn[lane] : 0u;
+        {   // row r keeps the splat only if it lies in front of the row's deepest contributor (pos < row_last_r)
+            const uint32_t pos = nib >> 4;
+            nib &= (pos < row_last0 ? 1u : 0u) | (pos < row_last1 ? 2u : 0u) | (pos < row_last2 ? 4u : 0u) | (pos < row_last3 ? 8u : 0u);
+        }
         const uint64_t m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u), m2 = __ballot(nib & 4u), m3 = __ballot(nib & 8u);
         const int len0 = __popcll(m0), len1 = __popcll(m1), len2 = __popcll(m2), len3 = __popcll(m3);
         // every entry past a queue's end reads 252 + row = "exhausted" (any value >= 64; distinct per row for the
@@ -730,7 +792,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
         if (nib & 2u) wb.ql[1][len1 - 1 - rank_below(m1)] = (uint8_t)lane;
         if (nib & 4u) wb.ql[2][len2 - 1 - rank_below(m2)] = (uint8_t)lane;
         if (nib & 8u) wb.ql[3][len3 - 1 - rank_below(m3)] = (uint8_t)lane;
-        const int trips = max(max(len0, len1), max(len2, len3));  // >= 1: every staged splat touches some row
+        const int trips = max(max(len0, len1), max(len2, len3));  // (0: nothing staged lies in front of its rows' deepest contributors -- one idle step)
         wave_lds_sync();
         GS2D_PROF_STAGE_END();
         // software pipeline: queue entries are read two trips ahead, records one trip ahead
@@ -809,8 +871,6 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
                     accum_depth_rec = fmaf(last_alpha, last_depth, (1.f - last_alpha) * accum_depth_rec);             \
                     last_depth = c_d;                                                                                 \
                     dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);                                    \
-                    accum_alpha_rec = fmaf(1.f - last_alpha, accum_alpha_rec, last_alpha);                            \
-                    dL_dalpha = fmaf(1 - accum_alpha_rec, dL_daccum, dL_dalpha);                                      \
                     if (ANY_DN) { /* backward.cu:392-397; the normal is not staged: rare path, read it from the record */ \
                         const float4 nn = rec[(size_t)__float_as_uint(cc.w) * GS2D_REC_F4 + 3];                       \
                         an0 = fmaf(last_alpha, ln0, (1.f - last_alpha) * an0); ln0 = nn.x;                            \
@@ -944,33 +1004,47 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, const uint2* __restrict__ ran
 
 namespace gs2d {
 
-void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
-                      const float* bg, float* out_color, float* out_others, float* pix_state, uint8_t* hits, uint8_t* hits4,
-                      int use_sa, float4* zero, size_t zero_n, hipStream_t s)
+void launch_blend_fwd(int W, int H, int K, const BlendFwdFrame* frames, const float* bg, int use_sa, size_t zero_n, hipStream_t s)
 {
     const int gx = (W + GS2D_TILE - 1) / GS2D_TILE, gy = (H + GS2D_TILE - 1) / GS2D_TILE;
     const size_t plane = (size_t)gx * gy * GS2D_TILE_PIX;
-    const int grid = GS2D_XCDS * ((gx * gy + GS2D_XCDS - 1) / GS2D_XCDS);
+    const int bpf = GS2D_XCDS * ((gx * gy + GS2D_XCDS - 1) / GS2D_XCDS);  // a multiple of 8: blockIdx % 8 picks the same XCD in every frame
+    if (K == 1) {
+        if (use_sa)
+            hipLaunchKernelGGL((blend_fwd_kernel<true, false>), dim3(bpf), dim3(256), 0, s, W, H, gx, gx * gy, bpf, bg, plane, zero_n, frames[0]);
+        else
+            hipLaunchKernelGGL((blend_fwd_kernel<false, false>), dim3(bpf), dim3(256), 0, s, W, H, gx, gx * gy, bpf, bg, plane, zero_n, frames[0]);
+        return;
+    }
+    BlendFwdBatch b;
+    for (int k = 0; k < K; k++) b.f[k] = frames[k];
+    for (int k = K; k < GS2D_MAX_BATCH; k++) b.f[k] = frames[0];
     if (use_sa)
-        hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, W, H, gx, gx * gy, ranges, point_list, rec,
-                           bg, out_color, out_others, pix_state, plane, hits, hits4, zero, zero_n);
+        hipLaunchKernelGGL((blend_fwd_kernel<true, true>), dim3(bpf * K), dim3(256), 0, s, W, H, gx, gx * gy, bpf, bg, plane, zero_n, b);
     else
-        hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, W, H, gx, gx * gy, ranges, point_list, rec,
-                           bg, out_color, out_others, pix_state, plane, hits, hits4, zero, zero_n);
+        hipLaunchKernelGGL((blend_fwd_kernel<false, true>), dim3(bpf * K), dim3(256), 0, s, W, H, gx, gx * gy, bpf, bg, plane, zero_n, b);
 }
 
-void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
-                      const float* bg, const float* pix_state, const uint8_t* hits, const float* dL_dpix,
-                      const float* dL_dothers, float* grad_rec, int use_sa, float* det_slots, float* clear12, int clear_n, hipStream_t s)
+void launch_blend_bwd(int W, int H, int K, const BlendBwdFrame* frames, const float* bg, int use_sa, float* clear12, int clear_n,
+                      hipStream_t s)
 {
     const int gx = (W + GS2D_TILE - 1) / GS2D_TILE, gy = (H + GS2D_TILE - 1) / GS2D_TILE;
     const size_t plane = (size_t)gx * gy * GS2D_TILE_PIX;
-    const int grid = GS2D_XCDS * ((gx * gy + GS2D_XCDS - 1) / GS2D_XCDS);
-#define GS2D_LAUNCH_BWD(SA, DET)                                                                                              \
-    hipLaunchKernelGGL((blend_bwd_kernel<SA, DET>), dim3(grid), dim3(256), 0, s, W, H, gx, gx * gy, ranges, point_list, rec, bg, \
-                       pix_state, plane, hits, dL_dpix, dL_dothers, grad_rec, det_slots, clear12, clear_n)
-    if (det_slots) { if (use_sa) GS2D_LAUNCH_BWD(true, true); else GS2D_LAUNCH_BWD(false, true); }
-    else { if (use_sa) GS2D_LAUNCH_BWD(true, false); else GS2D_LAUNCH_BWD(false, false); }
+    const int bpf = GS2D_XCDS * ((gx * gy + GS2D_XCDS - 1) / GS2D_XCDS);
+    const bool det = frames[0].det_slots != nullptr;
+#define GS2D_LAUNCH_BWD(SA, DET, BATCH, GRID, ARGS)                                                                       \
+    hipLaunchKernelGGL((blend_bwd_kernel<SA, DET, BATCH>), dim3(GRID), dim3(256), 0, s, W, H, gx, gx * gy, bpf, bg, plane,  \
+                       clear12, clear_n, ARGS)
+    if (K == 1) {
+        if (det) { if (use_sa) GS2D_LAUNCH_BWD(true, true, false, bpf, frames[0]); else GS2D_LAUNCH_BWD(false, true, false, bpf, frames[0]); }
+        else { if (use_sa) GS2D_LAUNCH_BWD(true, false, false, bpf, frames[0]); else GS2D_LAUNCH_BWD(false, false, false, bpf, frames[0]); }
+        return;
+    }
+    BlendBwdBatch b;
+    for (int k = 0; k < K; k++) b.f[k] = frames[k];
+    for (int k = K; k < GS2D_MAX_BATCH; k++) b.f[k] = frames[0];
+    // (the deterministic variant is single-frame only: gs2d_backward_batch refuses it)
+    if (use_sa) GS2D_LAUNCH_BWD(true, false, true, bpf * K, b); else GS2D_LAUNCH_BWD(false, false, true, bpf * K, b);
 #undef GS2D_LAUNCH_BWD
 }
 

@@ -209,18 +209,30 @@ bool launch_bin_by_tile(int R, int tiles, int nbits, const uint64_t* keys_in, co
 void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt,
                             uint32_t* vals_alt, int packed, int write_keys, hipStream_t s);
 void launch_tile_ranges(int R, const uint64_t* keys, uint2* ranges, int tiles, hipStream_t s);
+// Per-frame pointers of the blend kernels.  A launch handles K frames of the same size over the same Gaussians (K = 1: the
+// plain call; K > 1: gs2d_forward_batch / gs2d_backward_batch, one grid over K x tiles).
+#define GS2D_MAX_BATCH 8
+struct BlendFwdFrame {
+    const uint2* ranges; const uint32_t* point_list; const float4* rec;
+    float* out_color; float* out_others; float* pix_state;
+    uint8_t* hits; uint8_t* hits4;  // written by phase 0 (cull bits, gs2d_cull.h)
+    float4* zero;                   // the backward's gradient accumulator, cleared with the kernel's idle store slots
+};
+struct BlendFwdBatch { BlendFwdFrame f[GS2D_MAX_BATCH]; };
+struct BlendBwdFrame {
+    const uint2* ranges; const uint32_t* point_list; const float4* rec; const float* pix_state; const uint8_t* hits;
+    const float* dL_dpix; const float* dL_dothers; float* grad_rec;
+    float* det_slots;  // != nullptr selects the deterministic variant (single frame only): no atomics, per-(instance, quadrant)
+                       // partial records (GS2D_GRAD_FLOATS floats each, R * 4 of them, zero-initialised by the caller)
+};
+struct BlendBwdBatch { BlendBwdFrame f[GS2D_MAX_BATCH]; };
 // Writes hits (u16[4 * i + q] = the 2x2 pixel groups of quadrant q that instance i of the sorted list can touch, see
 // gs2d_cull.h) for every instance, then blends.  Also clears zero_n float4 at `zero` (the backward's gradient accumulator)
 // with its idle store slots.
-void launch_blend_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
-                      const float* bg, float* out_color, float* out_others, float* pix_state, uint8_t* hits, uint8_t* hits4,
-                      int use_sa, float4* zero, size_t zero_n, hipStream_t s);
-// clear12 (optional): 12 floats zeroed by the kernel (the pose-gradient sums the next stage accumulates into).
-// det_slots != nullptr selects the deterministic variant: no atomics, per-(instance, quadrant) partial records
-// (GS2D_GRAD_FLOATS floats each, R * 4 of them, zero-initialised by the caller) that launch_det_reduce then sums
-void launch_blend_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const float4* rec,
-                      const float* bg, const float* pix_state, const uint8_t* hits, const float* dL_dpix,
-                      const float* dL_dothers, float* grad_rec, int use_sa, float* det_slots, float* clear12, int clear_n, hipStream_t s);
+void launch_blend_fwd(int W, int H, int K, const BlendFwdFrame* frames, const float* bg, int use_sa, size_t zero_n, hipStream_t s);
+// clear12 (optional): clear_n floats zeroed by the kernel (the pose-gradient sums the next stage accumulates into).
+void launch_blend_bwd(int W, int H, int K, const BlendBwdFrame* frames, const float* bg, int use_sa, float* clear12, int clear_n,
+                      hipStream_t s);
 // deterministic mode: inv[unsorted instance] = sorted position, then grad_rec[g] = sum of g's slots in a fixed order
 void launch_det_reduce(int P, int R, int W, int H, const uint2* ranges, const uint32_t* point_list, const ushort4* rect,
                        const uint32_t* tiles_touched, const uint32_t* point_offsets, const uint8_t* hits,

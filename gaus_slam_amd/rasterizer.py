@@ -246,6 +246,120 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
 
 
+def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
+                              viewmatrices, projmatrices, image_height, image_width, sh, degree, camposs, use_sa, debug):
+    """K frames of the same size over the same Gaussians in one call (gs2d_forward_batch): per frame exactly what
+    rasterize_gaussians returns, the blend pass as ONE grid over the tiles of all frames.  viewmatrices / projmatrices:
+    [K,4,4] (or [K,16]), camposs: [K,3].  Returns (num_rendered list[K], out_color [K,3,H,W], out_others [K,7,H,W],
+    radii [K,P], geomBuffers, binningBuffers, imgBuffers: lists of K uint8 tensors)."""
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    for name, t in (("background", background), ("means3D", means3D), ("colors", colors), ("opacity", opacity),
+                    ("scales", scales), ("rotations", rotations), ("transMat_precomp", transMat_precomp),
+                    ("viewmatrices", viewmatrices), ("projmatrices", projmatrices), ("sh", sh), ("camposs", camposs)):
+        _check_cuda(t, name)
+    L = _lib.lib()
+    dev = means3D.device
+    K = viewmatrices.size(0)
+    if not 1 <= K <= _lib.MAX_FRAMES or projmatrices.size(0) != K or camposs.size(0) != K:
+        raise RuntimeError(f"need 1..{_lib.MAX_FRAMES} frames with one view matrix, projection matrix and camera position each")
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    alloc = torch.zeros if P == 0 else torch.empty
+    out_color = alloc((K, NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    out_others = alloc((K, 7, H, W), dtype=torch.float32, device=dev)
+    radii = alloc((K, P), dtype=torch.int32, device=dev)
+    chunks = [(_Chunk(dev), _Chunk(dev), _Chunk(dev)) for _ in range(K)]
+    counts = (C.c_int * K)()
+    rc = 0
+    try:
+        if P != 0:
+            M = sh.size(1) if sh.size(0) != 0 else 0
+            keep = [_f32c(t) for t in (background, means3D, sh, colors, opacity, scales, rotations, transMat_precomp)]
+            bg_, m3_, sh_, col_, op_, sc_, rot_, tm_ = keep
+            vm_ = _f32c(viewmatrices).reshape(K, 16)
+            pm_ = _f32c(projmatrices).reshape(K, 16)
+            cp_ = _f32c(camposs).reshape(K, 3)
+            io = (_lib.FrameIO * K)()
+            for k, (g, b, im) in enumerate(chunks):
+                io[k].geometry_alloc, io[k].geometry_user = g.cb, g.user
+                io[k].binning_alloc, io[k].binning_user = b.cb, b.user
+                io[k].image_alloc, io[k].image_user = im.cb, im.user
+                io[k].viewmatrix, io[k].projmatrix, io[k].cam_pos = vm_[k].data_ptr(), pm_[k].data_ptr(), cp_[k].data_ptr()
+                io[k].out_color, io[k].out_others, io[k].radii = out_color[k].data_ptr(), out_others[k].data_ptr(), radii[k].data_ptr()
+            with _on_device(dev):
+                rc = L.gs2d_forward_batch(K, io, P, int(degree), M, _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(op_),
+                                          _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(tm_), int(bool(use_sa)),
+                                          int(bool(debug)), counts, _stream_ptr(dev))
+    finally:
+        for trio in chunks:
+            for ch in trio:
+                ch.release()
+    if rc < 0:
+        raise RuntimeError(_lib.last_error())
+    return ([int(counts[k]) for k in range(K)], out_color, out_others, radii, [c[0].tensor for c in chunks],
+            [c[1].tensor for c in chunks], [c[2].tensor for c in chunks])
+
+
+def rasterize_gaussians_backward_batch(background, means3D, radii, colors, scales, rotations, scale_modifier, transMat_precomp,
+                                       viewmatrices, projmatrices, tan_fovxs, tan_fovys, dL_dout_color, dL_dout_others, sh,
+                                       degree, camposs, geomBuffers, Rs, binningBuffers, imageBuffers, use_sa, debug,
+                                       grad_sink=None, lean=False):
+    """gs2d_backward_batch: the backward of rasterize_gaussians_batch.  Returns a list of K tuples, frame k's being exactly
+    what rasterize_gaussians_backward returns for that frame (per-frame gradients; the caller sums them).
+    grad_sink: as in rasterize_gaussians_backward, for frame 0's parameter gradients."""
+    L = _lib.lib()
+    dev = means3D.device
+    P = means3D.size(0)
+    # dL_dout_color / dL_dout_others: [K,3,H,W] / [K,7,H,W] tensors or sequences of K per-frame tensors
+    K, H, W = len(dL_dout_color), dL_dout_color[0].size(1), dL_dout_color[0].size(2)
+    M = sh.size(1) if sh.size(0) != 0 else 0
+    z = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    outs = []
+    for k in range(K):
+        o = {"means3D": z(P, 3), "means2D": z(P, 3), "colors": z(P, NUM_CHANNELS), "normal": None if lean else z(P, 3),
+             "opacities": z(P, 1), "transMat": None if (lean and transMat_precomp.numel() == 0) else z(P, 9), "sh": z(P, M, 3),
+             "scales": z(P, 2), "rotations": z(P, 4)}
+        if k == 0 and grad_sink:
+            for name in ("means3D", "colors", "opacities", "scales", "rotations"):
+                sk = grad_sink.get(name)
+                if sk is None:
+                    continue
+                if sk.shape != o[name].shape or sk.dtype != torch.float32 or sk.device != dev or not sk.is_contiguous():
+                    raise RuntimeError(f"grad_sink[{name!r}] must be a contiguous fp32 {tuple(o[name].shape)} tensor on {dev}")
+                o[name] = sk.detach()
+        outs.append(o)
+    rc = 0
+    if P != 0:
+        keep = [_f32c(t) for t in (background, means3D, sh, colors, scales, rotations, transMat_precomp)]
+        bg_, m3_, sh_, col_, sc_, rot_, tm_ = keep
+        dc_ = [_f32c(dL_dout_color[k]) for k in range(K)]
+        do_ = [_f32c(dL_dout_others[k]) for k in range(K)]
+        vm_ = _f32c(viewmatrices).reshape(K, 16)
+        pm_ = _f32c(projmatrices).reshape(K, 16)
+        cp_ = _f32c(camposs).reshape(K, 3)
+        radii_ = radii.contiguous()
+        fr = (_lib.FrameGrad * K)()
+        for k in range(K):
+            f, o = fr[k], outs[k]
+            f.viewmatrix, f.projmatrix, f.campos = vm_[k].data_ptr(), pm_[k].data_ptr(), cp_[k].data_ptr()
+            f.tan_fovx, f.tan_fovy = float(tan_fovxs[k]), float(tan_fovys[k])
+            f.radii = radii_[k].data_ptr()
+            f.geom_buffer, f.binning_buffer, f.img_buffer = _ptr(geomBuffers[k]), _ptr(binningBuffers[k]), _ptr(imageBuffers[k])
+            f.num_rendered = int(Rs[k])
+            f.dL_dpix, f.dL_depths = dc_[k].data_ptr(), do_[k].data_ptr()
+            f.dL_dmean2D, f.dL_dnormal, f.dL_dopacity = o["means2D"].data_ptr(), _ptr(o["normal"]), o["opacities"].data_ptr()
+            f.dL_dcolor, f.dL_dmean3D, f.dL_dtransMat = o["colors"].data_ptr(), o["means3D"].data_ptr(), _ptr(o["transMat"])
+            f.dL_dsh, f.dL_dscale, f.dL_drot = _ptr(o["sh"]), o["scales"].data_ptr(), o["rotations"].data_ptr()
+        with _on_device(dev):
+            rc = L.gs2d_backward_batch(K, fr, P, int(degree), M, _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(sc_),
+                                       float(scale_modifier), _ptr(rot_), _ptr(tm_), int(bool(use_sa)), int(bool(debug)),
+                                       _stream_ptr(dev))
+    if rc < 0:
+        raise RuntimeError(_lib.last_error())
+    return [(o["means2D"], o["colors"], o["opacities"], o["means3D"], o["transMat"], o["sh"], o["scales"], o["rotations"])
+            for o in outs]
+
+
 def set_deterministic(on=True):
     """Opt-in deterministic backward (gs2d_set_deterministic): no float atomics, gradients bit-identical from run to run.
     Process-wide; keep it unchanged between a forward and its backward."""
@@ -362,6 +476,85 @@ class _RasterizeGaussians(torch.autograd.Function):
                 grad_cov3Ds_precomp, None)
 
 
+_CAMERA_STACKS = []  # [(settings tuple, vms, pms, cps)]: the stacked per-frame matrices of recently used frame sets
+
+
+def _stacked_cameras(settings_list):
+    """[K,16] view / projection matrices and [K,3] camera positions of a frame set, validated and stacked ONCE per set of
+    settings objects (identity-keyed, the last 8 sets are kept): a BA loop renders the same keyframes step after step, and
+    neither the three stack kernels nor a device-synchronising background comparison belong on its critical path."""
+    key = tuple(settings_list)
+    for ent in _CAMERA_STACKS:
+        if len(ent[0]) == len(key) and all(a is b for a, b in zip(ent[0], key)):
+            return ent[1], ent[2], ent[3]
+    rs0 = key[0]
+    for rs in key[1:]:
+        same = (rs.image_height == rs0.image_height and rs.image_width == rs0.image_width and rs.use_sa == rs0.use_sa
+                and rs.sh_degree == rs0.sh_degree and rs.scale_modifier == rs0.scale_modifier and rs.debug == rs0.debug
+                and (rs.bg is rs0.bg or torch.equal(rs.bg, rs0.bg)))
+        if not same:
+            raise RuntimeError("batched frames must share image size, background, sh_degree, scale_modifier, use_sa and debug")
+    vms = torch.stack([rs.viewmatrix.reshape(16) for rs in key]).float().contiguous()
+    pms = torch.stack([rs.projmatrix.reshape(16) for rs in key]).float().contiguous()
+    cps = torch.stack([rs.campos.reshape(3) for rs in key]).float().contiguous()
+    _CAMERA_STACKS.append((key, vms, pms, cps))
+    if len(_CAMERA_STACKS) > 8:
+        _CAMERA_STACKS.pop(0)
+    return vms, pms, cps
+
+
+class _RasterizeGaussiansBatch(torch.autograd.Function):
+    """_RasterizeGaussians over K cameras at once (same Gaussians, same image size): returns (radii [K,P], K colour images,
+    K allmaps); the gradient of every input is the sum over the frames (added in frame order, as K separate calls accumulate)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings_list):
+        rs0 = settings_list[0]
+        vms, pms, cps = _stacked_cameras(settings_list)
+        Rs, color, depth, radii, geoms, bins, imgs = rasterize_gaussians_batch(
+            rs0.bg, means3D, colors_precomp, opacities, scales, rotations, rs0.scale_modifier, cov3Ds_precomp, vms, pms,
+            rs0.image_height, rs0.image_width, sh, rs0.sh_degree, cps, rs0.use_sa, rs0.debug)
+        ctx.settings_list = settings_list
+        ctx.Rs = Rs
+        K = ctx.K = len(settings_list)
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, vms, pms, cps,
+                              *geoms, *bins, *imgs)
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
+        ctx.image_shape = (color.shape[1:], depth.shape[1:])
+        # one output per frame (slices of the stacked buffers made here, so autograd sees K independent tensors and hands the
+        # backward K independent gradients -- a stacked output indexed by the caller would route every frame's gradient through
+        # a zero-filled [K, ...] tensor and an add)
+        return (radii,) + tuple(color[k] for k in range(K)) + tuple(depth[k] for k in range(K))
+
+    @staticmethod
+    def backward(ctx, grad_radii, *grads):
+        K = ctx.K
+        rs0 = ctx.settings_list[0]
+        saved = ctx.saved_tensors
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, vms, pms, cps = saved[:10]
+        geoms, bins, imgs = saved[10:10 + K], saved[10 + K:10 + 2 * K], saved[10 + 2 * K:10 + 3 * K]
+        zeros = lambda shape: torch.zeros(shape, dtype=torch.float32, device=means3D.device)
+        grad_out_color = [g if g is not None else zeros(ctx.image_shape[0]) for g in grads[:K]]
+        grad_depth = [g if g is not None else zeros(ctx.image_shape[1]) for g in grads[K:]]
+        sink, chunk_rows, on_chunk = _take_sink()
+        if on_chunk is not None:
+            raise RuntimeError("chunked (overlapped) reduction is a one-keyframe-per-rank feature; the batched backward has none")
+        per = rasterize_gaussians_backward_batch(
+            rs0.bg, means3D, radii, colors_precomp, scales, rotations, rs0.scale_modifier, cov3Ds_precomp, vms, pms,
+            [rs.tanfovx for rs in ctx.settings_list], [rs.tanfovy for rs in ctx.settings_list], grad_out_color, grad_depth, sh,
+            rs0.sh_degree, cps, geoms, ctx.Rs, bins, imgs, rs0.use_sa, rs0.debug, grad_sink=sink, lean=True)
+        total = list(per[0])
+        for k in range(1, K):  # frame order: the same sums K separate backwards accumulate
+            for i, g in enumerate(per[k]):
+                if g is not None and total[i] is not None:
+                    total[i].add_(g)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = total
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, None)
+
+
 def rasterize_gaussians_apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                               raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
@@ -415,3 +608,31 @@ class GaussianRasterizer(nn.Module):
             cov3D_precomp = empty()
         return rasterize_gaussians_apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                          cov3D_precomp, rs)
+
+
+class GaussianRasterizerBatch(nn.Module):
+    """GaussianRasterizer for K cameras of the same image size in one call (no counterpart in the reference; for BA ranks
+    that hold several keyframes, gaus_slam_amd/ba_shard.py).  forward(...) takes the arguments of
+    GaussianRasterizer.forward and returns (colors: K tensors [3,H,W], radii [K,P], allmaps: K tensors [7,H,W])."""
+
+    def __init__(self, settings_list):
+        super().__init__()
+        self.settings_list = list(settings_list)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = lambda: torch.empty(0, dtype=torch.float32, device=means3D.device)
+        shs = empty() if shs is None else shs
+        colors_precomp = empty() if colors_precomp is None else colors_precomp
+        scales = empty() if scales is None else scales
+        rotations = empty() if rotations is None else rotations
+        cov3D_precomp = empty() if cov3D_precomp is None else cov3D_precomp
+        K = len(self.settings_list)
+        out = _RasterizeGaussiansBatch.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                             cov3D_precomp, self.settings_list)
+        return out[1:1 + K], out[0], out[1 + K:]

@@ -3,7 +3,7 @@ weight-norm / outlier step of render/__init__.py:46-49.  Provided so benches and
 way the reference callers do, without importing the reference."""
 import torch
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, GaussianRasterizerBatch
 
 
 def settings_from_camera(cam, device, bg=None, use_sa=True, sh_degree=0, debug=False):
@@ -30,3 +30,15 @@ def render(settings, means3D, means2D, opacities, shs=None, colors_precomp=None,
         outlier = torch.logical_or(d > depth_far, d < depth_near)
         pkg["render_depth"] = torch.where(outlier, torch.zeros_like(d), d)
     return pkg
+
+
+def render_batch(settings_list, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                 cov3D_precomp=None):
+    """render() for K cameras of the same image size in one operator call (GaussianRasterizerBatch): a list of K packages
+    with the keys of render()."""
+    color, radius, allmap = GaussianRasterizerBatch(settings_list)(
+        means3D, means2D, opacities=opacities, shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
+        cov3D_precomp=cov3D_precomp)
+    return [{"render_color": color[k], "radius": radius[k], "means2D": means2D, "allmap": allmap[k],
+             "render_depth": allmap[k][0:1], "render_alpha": allmap[k][1:2], "render_normal": allmap[k][2:5],
+             "render_middepth": allmap[k][5:6], "render_dist": allmap[k][6:7]} for k in range(len(settings_list))]

@@ -177,6 +177,48 @@ int gs2d_backward_staged(
     const float* pose_quat, float* dL_dpose /* [12] */, void* stream);
 
 /*
+ * Batched keyframes (no counterpart in the reference, whose backend renders one keyframe per step, slam/Backend.py:101-128):
+ * K frames of the same size over the SAME Gaussians -- what a bundle-adjustment rank holds when keyframes outnumber GPUs
+ * (gaus_slam_amd/ba_shard.py).  Per frame the calls do exactly what gs2d_forward / gs2d_backward do, with the same
+ * per-frame scratch chunks and bit-identical per-frame outputs; the two blend passes run as ONE grid over the tiles of all
+ * K frames, so the next frame's tiles fill the SIMDs the previous frame's last waves leave idle, and the host waits once
+ * for all K num_rendered values.  Mapping / BA regime only: no fused pose, no deterministic variant (use the per-frame
+ * calls for those).  1 <= K <= GS2D_MAX_FRAMES.
+ */
+#define GS2D_MAX_FRAMES 8
+typedef struct gs2d_frame_io {       /* per-frame arguments of gs2d_forward (same meaning) */
+    gs2d_alloc_fn geometry_alloc; void* geometry_user;
+    gs2d_alloc_fn binning_alloc; void* binning_user;
+    gs2d_alloc_fn image_alloc; void* image_user;
+    const float* viewmatrix; const float* projmatrix; const float* cam_pos;
+    float* out_color;                /* [3,H,W] */
+    float* out_others;               /* [7,H,W] */
+    int* radii;                      /* [P] */
+} gs2d_frame_io;
+/* num_rendered[k] receives frame k's instance count.  Returns 0 or < 0 on error. */
+int gs2d_forward_batch(
+    int K, const gs2d_frame_io* frames, int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
+    float scale_modifier, const float* rotations, const float* transMat_precomp, int use_sa, int debug,
+    int* num_rendered /* [K], host */, void* stream);
+
+typedef struct gs2d_frame_grad {     /* per-frame arguments of gs2d_backward (same meaning) */
+    const float* viewmatrix; const float* projmatrix; const float* campos;
+    float tan_fovx, tan_fovy;
+    const int* radii;
+    char* geom_buffer; char* binning_buffer; char* img_buffer;
+    int num_rendered;
+    const float* dL_dpix;            /* [3,H,W] */
+    const float* dL_depths;          /* [7,H,W] */
+    float* dL_dmean2D; float* dL_dnormal; float* dL_dopacity; float* dL_dcolor; float* dL_dmean3D;
+    float* dL_dtransMat; float* dL_dsh; float* dL_dscale; float* dL_drot;
+} gs2d_frame_grad;
+int gs2d_backward_batch(
+    int K, const gs2d_frame_grad* frames, int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+    const float* rotations, const float* transMat_precomp, int use_sa, int debug, void* stream);
+
+/*
  * Deterministic backward (opt-in, process-wide; off by default).  The reference accumulates per-Gaussian gradients with
  * float atomics (backward.cu:343,396,441-460), so its gradients differ from run to run in the last bits, and so do this
  * library's by default.  With the switch on, the backward uses no atomics: every (instance, quadrant) pair is summed by

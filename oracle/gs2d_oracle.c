@@ -568,11 +568,12 @@ void orc_blend_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t* 
                    const uint32_t* n_contrib, const float* dL_dpixels, const float* dL_depths,
                    const float* median_depth, const float* depth_std, int use_sa,
                    float* dL_dtransMat, float* dL_dmean2D /* [P,3] */, float* dL_dnormal3D,
-                   float* dL_dopacity, float* dL_dcolors)
+                   float* dL_dopacity, float* dL_dcolors, const double* extra_acc /* NULL or [P][20] (orc_blend_bwd_pixel) */)
 {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const size_t HW = (size_t)H * W;
     double* acc = (double*)calloc((size_t)P * ACC_STRIDE + 1, sizeof(double));
+    if (extra_acc) memcpy(acc, extra_acc, (size_t)P * ACC_STRIDE * sizeof(double));
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gx * gy; tile++) {
         const int tx = tile % gx, ty = tile / gx;
@@ -722,6 +723,205 @@ void orc_blend_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t* 
         dL_dopacity[g] = (float)a[17];
     }
     free(acc);
+}
+
+/*
+ * Backward blend of ONE pixel under one outcome of its near-threshold forward decisions (the `flipmask` numbering of
+ * orc_blend_fwd_pixel): the forward walk is repeated with those decisions flipped, every splat's outcome is recorded
+ * (skipped / contributes, ray-splat or low-pass branch, T > 0.5), and the backward recurrence of orc_blend_bwd then runs on
+ * the RECORDED outcomes instead of re-deriving them -- i.e. the gradient the reference's backward would produce had its
+ * arithmetic fallen on that side of the thresholds.  Lets the parity tests give knife-edge pixels an upstream gradient
+ * (tests/test_gpu_round3.py) instead of masking them out.  Contributions are ADDED to acc (20 doubles per Gaussian, the
+ * layout of orc_blend_bwd).  dL_dpix: 3 floats, dL_doth: 7 floats (this pixel's upstream gradients).  Returns the number
+ * of near-threshold decisions met (as orc_blend_fwd_pixel does).
+ */
+int orc_blend_bwd_pixel(int W, int H, int px, int py, const uint32_t* ranges, const uint32_t* point_list,
+                        const float* means2D, const float* features, const float* transMats,
+                        const float* normal_opacity, const float* bg, int use_sa, float knife, uint32_t flipmask,
+                        const float* dL_dpix, const float* dL_doth, double* acc)
+{
+    const int gx = (W + TILE - 1) / TILE;
+    (void)H;
+    const int tile = (py / TILE) * gx + (px / TILE);
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    const uint32_t n = r1 - r0;
+    const float pxf = (float)px, pyf = (float)py;
+    /* per list position: 0 = skipped, 1 = contributes on the ray-splat branch, 2 = contributes on the low-pass branch */
+    uint8_t* outcome = (uint8_t*)calloc(n + 1, 1);
+    float T = 1.0f, Dp = 0, M1 = 0, M2 = 0, D2 = 0, median_depth = 0;
+    uint32_t contributor = 0, last_contributor = 0, median_contributor = 0;
+    int nk = 0;
+#define KNIFE_DECIDE(cond, a, b)                                                           \
+    ({ int d_ = (cond);                                                                     \
+       if (relm((a), (b)) <= knife) { if (nk < 32 && ((flipmask >> nk) & 1u)) d_ = !d_; nk++; } \
+       d_; })
+    for (uint32_t it = r0; it < r1; it++) { /* the forward of orc_blend_fwd_pixel, recording outcomes */
+        contributor++;
+        const uint32_t g = point_list[it];
+        const float* Tm = transMats + 9 * (size_t)g;
+        const float Tu[3] = {Tm[0], Tm[1], Tm[2]}, Tv[3] = {Tm[3], Tm[4], Tm[5]}, Tw[3] = {Tm[6], Tm[7], Tm[8]};
+        const float k[3] = {fmaf(pxf, Tw[0], -Tu[0]), fmaf(pxf, Tw[1], -Tu[1]), fmaf(pxf, Tw[2], -Tu[2])};
+        const float l[3] = {fmaf(pyf, Tw[0], -Tv[0]), fmaf(pyf, Tw[1], -Tv[1]), fmaf(pyf, Tw[2], -Tv[2])};
+        const float p0 = fmaf(k[1], l[2], -(k[2] * l[1]));
+        const float p1 = fmaf(k[2], l[0], -(k[0] * l[2]));
+        const float p2 = fmaf(k[0], l[1], -(k[1] * l[0]));
+        if (p2 == 0.0f) continue;
+        const float ip = 1.0f / p2;
+        const float s0 = p0 * ip, s1 = p1 * ip;
+        const float rho3d = fmaf(s0, s0, s1 * s1);
+        const float d0 = means2D[2 * (size_t)g] - pxf, d1 = means2D[2 * (size_t)g + 1] - pyf;
+        const float rho2d = FILTER_INV_SQ * fmaf(d0, d0, d1 * d1);
+        const float mx = fmaxf(rho3d, rho2d);
+        int ray = rho3d <= rho2d;
+        if (mx > 0 && fabsf(rho3d - rho2d) / mx <= knife) { if (nk < 32 && ((flipmask >> nk) & 1u)) ray = !ray; nk++; }
+        const float rho = ray ? rho3d : rho2d;
+        float depth = ray ? fmaf(s0, Tw[0], fmaf(s1, Tw[1], Tw[2])) : Tw[2];
+        if (KNIFE_DECIDE(depth < NEAR_N, depth, NEAR_N)) continue;
+        const float* no = normal_opacity + 4 * (size_t)g;
+        const float power = -0.5f * rho;
+        if (power > 0.0f) continue;
+        const float alpha = fmin_c(0.99f, no[3] * expf(power));
+        if (KNIFE_DECIDE(alpha < 1.0f / 255.0f, alpha, 1.0f / 255.0f)) continue;
+        const float test_T = T * (1 - alpha);
+        if (KNIFE_DECIDE(test_T < 0.0001f, test_T, 0.0001f)) break;
+        const float w = alpha * T;
+        if (KNIFE_DECIDE(T > 0.5f, T, 0.5f)) { median_depth = depth; median_contributor = contributor; }
+        if (use_sa) {
+            if (Dp > 0) {
+                const float exp_depth = median_depth;
+                float exp_std = fmaf(fmaf(-2.0f * Dp, exp_depth, D2), 1.0f / (1 - T), exp_depth * exp_depth);
+                exp_std = fmax_c(exp_std, 1e-7f);
+                const float e = exp_depth - depth;
+                const float conf = expf(-(e * e) * (1.0f / (4 * exp_std)));
+                depth = fmaf(conf, depth, (1 - conf) * exp_depth);
+            }
+            Dp = fmaf(depth, w, Dp);
+            D2 = fmaf(depth * depth, w, D2);
+        } else {
+            const float m = (FAR_N / (FAR_N - NEAR_N)) * (1 - NEAR_N * (1.0f / depth));
+            Dp = fmaf(depth, w, Dp);
+            M1 = fmaf(m, w, M1);
+            M2 = fmaf(m * m, w, M2);
+        }
+        T = test_T;
+        last_contributor = contributor;
+        outcome[it - r0] = ray ? 1 : 2;
+    }
+#undef KNIFE_DECIDE
+    /* the per-pixel state the forward hands to the backward (forward.cu:441-466) */
+    const float T_final = T;
+    const float mm = median_depth;
+    const float mstd = fmaf(median_depth * median_depth, 1 - T, fmaf(-2.0f * median_depth, Dp, D2));
+    const float final_D = M1, final_D2 = M2, final_A = 1 - T_final;
+    const float dL_ddepth = dL_doth[0], dL_daccum = dL_doth[1], dL_dreg = dL_doth[6], dL_dmedian_depth = dL_doth[5];
+    const float dL_dnormal2D[3] = {dL_doth[2], dL_doth[3], dL_doth[4]};
+    float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0}, last_normal[3] = {0, 0, 0}, accum_normal_rec[3] = {0, 0, 0};
+    float last_depth = 0, accum_depth_rec = 0, accum_alpha_rec = 0, last_dL_dT = 0, last_alpha = 0;
+    const float bg_dot = fmaf(bg[2], dL_dpix[2], fmaf(bg[1], dL_dpix[1], bg[0] * dL_dpix[0]));
+    const float sa_k = 1.0f / (4 * fmax_c(mstd * (1.0f / (1 - T_final)), 1e-7f));
+    const float c1 = FAR_N / (FAR_N - NEAR_N);
+    contributor = n;
+    for (uint32_t it = r1; it-- > r0;) { /* the recurrence of orc_blend_bwd on the recorded outcomes */
+        contributor--;
+        if (contributor >= last_contributor) continue;
+        const int oc = outcome[it - r0];
+        if (oc == 0) continue;
+        const int ray = oc == 1;
+        const uint32_t g = point_list[it];
+        const float* Tm = transMats + 9 * (size_t)g;
+        const float Tu[3] = {Tm[0], Tm[1], Tm[2]}, Tv[3] = {Tm[3], Tm[4], Tm[5]}, Tw[3] = {Tm[6], Tm[7], Tm[8]};
+        const float k[3] = {fmaf(pxf, Tw[0], -Tu[0]), fmaf(pxf, Tw[1], -Tu[1]), fmaf(pxf, Tw[2], -Tu[2])};
+        const float l[3] = {fmaf(pyf, Tw[0], -Tv[0]), fmaf(pyf, Tw[1], -Tv[1]), fmaf(pyf, Tw[2], -Tv[2])};
+        const float p0 = fmaf(k[1], l[2], -(k[2] * l[1]));
+        const float p1 = fmaf(k[2], l[0], -(k[0] * l[2]));
+        const float p2 = fmaf(k[0], l[1], -(k[1] * l[0]));
+        const float ip = 1.0f / p2;
+        const float s0 = p0 * ip, s1 = p1 * ip;
+        const float rho3d = fmaf(s0, s0, s1 * s1);
+        const float d0 = means2D[2 * (size_t)g] - pxf, d1 = means2D[2 * (size_t)g + 1] - pyf;
+        const float rho2d = FILTER_INV_SQ * fmaf(d0, d0, d1 * d1);
+        const float rho = ray ? rho3d : rho2d;
+        float c_d = ray ? fmaf(s0, Tw[0], fmaf(s1, Tw[1], Tw[2])) : Tw[2];
+        const float* no = normal_opacity + 4 * (size_t)g;
+        const float G = expf(-0.5f * rho);
+        const float alpha = fmin_c(0.99f, no[3] * G);
+        const float ioma = 1.0f / (1.f - alpha);
+        T = T * ioma;
+        const float w = alpha * T;
+        float dL_dalpha = 0.0f;
+        for (int ch = 0; ch < 3; ch++) {
+            const float c = features[3 * (size_t)g + ch];
+            accum_rec[ch] = fmaf(last_alpha, last_color[ch], (1.f - last_alpha) * accum_rec[ch]);
+            last_color[ch] = c;
+            dL_dalpha = fmaf(c - accum_rec[ch], dL_dpix[ch], dL_dalpha);
+            acc[(size_t)g * ACC_STRIDE + ch] += (double)(w * dL_dpix[ch]);
+        }
+        float conf = 1;
+        if (use_sa) {
+            if (T < 0.5f) {
+                const float dm = c_d - mm;
+                conf = expf(-(dm * dm) * sa_k);
+            }
+            c_d = fmaf(c_d, conf, mm * (1 - conf));
+        }
+        float dL_dz = 0.0f, dL_dweight;
+        if (contributor == median_contributor - 1u) dL_dz = dL_dmedian_depth;
+        if (use_sa) {
+            const float dm = c_d - mm;
+            dL_dweight = (dm * dm) * dL_dreg;
+            dL_dalpha += dL_dweight - last_dL_dT;
+            last_dL_dT = fmaf(dL_dweight, alpha, (1 - alpha) * last_dL_dT);
+            dL_dz = fmaf(conf * 2.0f * w * dm, dL_dreg, dL_dz);
+        } else {
+            const float icd = 1.0f / c_d;
+            const float m_d = c1 * (1 - NEAR_N * icd);
+            const float dmd_dd = (c1 * NEAR_N) * (icd * icd);
+            dL_dweight = fmaf(m_d * m_d, final_A, fmaf(-2.0f * m_d, final_D, final_D2)) * dL_dreg;
+            dL_dalpha += dL_dweight - last_dL_dT;
+            last_dL_dT = fmaf(dL_dweight, alpha, (1 - alpha) * last_dL_dT);
+            const float dL_dmd = 2.0f * w * fmaf(m_d, final_A, -final_D) * dL_dreg;
+            dL_dz = fmaf(dL_dmd, dmd_dd, dL_dz);
+        }
+        accum_depth_rec = fmaf(last_alpha, last_depth, (1.f - last_alpha) * accum_depth_rec);
+        last_depth = c_d;
+        dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);
+        accum_alpha_rec = fmaf(1.f - last_alpha, accum_alpha_rec, last_alpha);
+        dL_dalpha = fmaf(1 - accum_alpha_rec, dL_daccum, dL_dalpha);
+        for (int ch = 0; ch < 3; ch++) {
+            accum_normal_rec[ch] = fmaf(last_alpha, last_normal[ch], (1.f - last_alpha) * accum_normal_rec[ch]);
+            last_normal[ch] = no[ch];
+            dL_dalpha = fmaf(no[ch] - accum_normal_rec[ch], dL_dnormal2D[ch], dL_dalpha);
+            acc[(size_t)g * ACC_STRIDE + 3 + ch] += (double)(w * dL_dnormal2D[ch]);
+        }
+        dL_dalpha *= T;
+        last_alpha = alpha;
+        dL_dalpha = fmaf(-T_final * ioma, bg_dot, dL_dalpha);
+        const float dL_dG = no[3] * dL_dalpha;
+        dL_dz = fmaf(conf * w, dL_ddepth, dL_dz);
+        if (ray) {
+            const float gG = dL_dG * -G;
+            const float dL_ds0 = fmaf(gG, s0, dL_dz * Tw[0]);
+            const float dL_ds1 = fmaf(gG, s1, dL_dz * Tw[1]);
+            const float dsx = dL_ds0 * ip, dsy = dL_ds1 * ip;
+            const float dp2 = -fmaf(dsx, s0, dsy * s1);
+            const float dk[3] = {fmaf(l[1], dp2, -(l[2] * dsy)), fmaf(l[2], dsx, -(l[0] * dp2)), fmaf(l[0], dsy, -(l[1] * dsx))};
+            const float dl[3] = {fmaf(dsy, k[2], -(dp2 * k[1])), fmaf(dp2, k[0], -(dsx * k[2])), fmaf(dsx, k[1], -(dsy * k[0]))};
+            const float dz_dTw[3] = {dL_dz * s0, dL_dz * s1, dL_dz};
+            for (int i = 0; i < 3; i++) {
+                acc[(size_t)g * ACC_STRIDE + 6 + i] += (double)(-dk[i]);
+                acc[(size_t)g * ACC_STRIDE + 9 + i] += (double)(-dl[i]);
+                acc[(size_t)g * ACC_STRIDE + 12 + i] += (double)fmaf(pxf, dk[i], fmaf(pyf, dl[i], dz_dTw[i]));
+            }
+        } else {
+            const float t = dL_dG * (-G * FILTER_INV_SQ);
+            acc[(size_t)g * ACC_STRIDE + 15] += (double)(t * d0);
+            acc[(size_t)g * ACC_STRIDE + 16] += (double)(t * d1);
+            acc[(size_t)g * ACC_STRIDE + 14] += (double)dL_dz;
+        }
+        acc[(size_t)g * ACC_STRIDE + 17] += (double)(G * dL_dalpha);
+    }
+    free(outcome);
+    return nk;
 }
 
 /* backward.cu:20-139 (SH backward); adds the view-direction term into dL_dmeans. */

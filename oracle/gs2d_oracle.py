@@ -188,18 +188,41 @@ def pixel_variants(st, px, py, knife, max_decisions=6):
                         median_contributor=int(out[11]), final_T=float(out[12]))
 
     nk, base = one(0)
+    base["mask"] = 0
     if nk == 0 or nk > max_decisions:
         return nk, [base]
-    return nk, [base] + [one(m)[1] for m in range(1, 1 << nk)]
+    out = [base]
+    for m in range(1, 1 << nk):
+        v = one(m)[1]
+        v["mask"] = m
+        out.append(v)
+    return nk, out
 
 
-def backward(st, dL_dcolor, dL_dallmap):
+def backward(st, dL_dcolor, dL_dallmap, pixel_overrides=None, knife=0.0):
     """Backward for a forward() state.  Returns the 8 gradients of
-    RAST/rasterize_points.cu:238 (+ the internal dL_dnormal)."""
+    RAST/rasterize_points.cu:238 (+ the internal dL_dnormal).
+    pixel_overrides (optional): list of (px, py, flipmask) -- those pixels take part under the given outcome of their
+    near-threshold decisions (the numbering of pixel_variants, same `knife`) instead of the oracle's own outcome: their
+    upstream gradient is removed from the plain pass and their contribution comes from orc_blend_bwd_pixel."""
     L = lib()
     P, W, H, M = st["P"], st["W"], st["H"], st["M"]
     dL_dcolor = _f32(dL_dcolor).reshape(3, H, W)
     dL_dallmap = _f32(dL_dallmap).reshape(7, H, W)
+    extra = None
+    if pixel_overrides and P > 0:
+        features0 = st["colors_precomp"] if st["colors_precomp"] is not None else st["rgb"]
+        tm0 = st["transMat_precomp"] if st["transMat_precomp"] is not None else st["transMats"]
+        extra = np.zeros((P, 20), np.float64)
+        dL_dcolor, dL_dallmap = dL_dcolor.copy(), dL_dallmap.copy()
+        L.orc_blend_bwd_pixel.restype = C.c_int
+        for (x, y, mask) in pixel_overrides:
+            gp = np.ascontiguousarray(dL_dcolor[:, y, x]); go = np.ascontiguousarray(dL_dallmap[:, y, x])
+            L.orc_blend_bwd_pixel(C.c_int(W), C.c_int(H), C.c_int(int(x)), C.c_int(int(y)), _p(st["ranges"]), _p(st["point_list"]),
+                                  _p(st["means2D"]), _p(features0), _p(tm0), _p(st["normal_opacity"]), _p(st["bg"]),
+                                  C.c_int(int(st["use_sa"])), C.c_float(knife), C.c_uint32(int(mask)), _p(gp), _p(go), _p(extra))
+            dL_dcolor[:, y, x] = 0
+            dL_dallmap[:, y, x] = 0
     g = dict(
         dL_dmeans3D=np.zeros((P, 3), np.float32), dL_dmeans2D=np.zeros((P, 3), np.float32),
         dL_dcolors=np.zeros((P, 3), np.float32), dL_dnormal=np.zeros((P, 3), np.float32),
@@ -215,7 +238,7 @@ def backward(st, dL_dcolor, dL_dallmap):
                     _p(st["final_T"]), _p(st["n_contrib"]), _p(dL_dcolor), _p(dL_dallmap),
                     _p(st["median_depth"]), _p(st["depth_std"]), C.c_int(int(st["use_sa"])),
                     _p(g["dL_dtransMat"]), _p(g["dL_dmeans2D"]), _p(g["dL_dnormal"]),
-                    _p(g["dL_dopacity"]), _p(g["dL_dcolors"]))
+                    _p(g["dL_dopacity"]), _p(g["dL_dcolors"]), _p(extra))
     g["dL_dtransMat_blend"] = g["dL_dtransMat"].copy()
     g["dL_dmeans2D_blend"] = g["dL_dmeans2D"].copy()
     L.orc_preprocess_bwd(C.c_int(P), C.c_int(st["D"]), C.c_int(M), _p(st["means3D"]), _p(tm),

@@ -15,9 +15,9 @@ keep = [np.ascontiguousarray(st[k]) for k in ("ranges", "point_list", "means2D",
 td = tempfile.mkdtemp()
 print(f"# trips per frame, {W}x{H} / {P} Gaussians, mapping regime (kernel counters: forward 957 499 / backward 957 155 with four 4x4 groups, BS 64;")
 print("# forward 716 435 with sixteen 2x2 groups, BS 64)")
-for bs in (64, 56, 48):
+for bs in (64,):
     so = os.path.join(td, f"gt{bs}.so")
     subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", f"-DBS={bs}", os.path.join(ROOT, "scripts", "dev", "group_trips.c"), "-o", so, "-lm"])
-    out = np.zeros(7)
+    out = np.zeros(9)
     C.CDLL(so).trip8(W, H, *[p(a) for a in keep], p(out))
-    print(f"batch {bs}: 4 groups of 4x4 {int(out[0])} | 8 groups of 4x2 {int(out[1])} | 8 groups of 2x4 {int(out[2])} | 16 groups of 2x2 {int(out[3])} | 32 groups of 2x1 {int(out[5])} | 64 single pixels {int(out[6])} | staged splats {int(out[4])}")
+    print(f"batch {bs}: 4 groups of 4x4 {int(out[0])} | 8 groups of 4x2 {int(out[1])} | 8 groups of 2x4 {int(out[2])} | 16 groups of 2x2 {int(out[3])} | 32 groups of 2x1 {int(out[5])} | 64 single pixels {int(out[6])} | staged splats {int(out[4])} | group-level last contributor: 4x4 {int(out[7])}, 2x2 {int(out[8])}")

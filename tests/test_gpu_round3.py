@@ -1,5 +1,7 @@
 """Round-3 GPU tests: the forward records behind the mode flags (deterministic / binning) and the "accumulator is
 clean" token, exercised the ways a caller can get them wrong."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -146,3 +148,76 @@ def test_deterministic_pose_gradient_is_bit_identical():
     assert np.abs(g1[:3]).max() > 0 and np.all(g1[3] == 0)
     assert np.array_equal(g1.view(np.uint32), g2.view(np.uint32)) and np.array_equal(g1.view(np.uint32), g3.view(np.uint32))
     assert np.abs(g1 - g_atomic).max() <= 1e-4 * np.abs(g_atomic).max()
+
+
+IMG_TOL, GRAD_TOL, MID_TOL, KNIFE = 1e-4, 1e-4, 1e-3, 2e-5
+ALL_GRADS = ["dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dtransMat", "dL_dscales", "dL_drotations", "dL_dmeans2D"]
+
+
+@pytest.mark.parametrize("use_sa", [True, False])
+def test_backward_parity_includes_knife_edge_pixels_and_mid_magnitude_entries(oracle, use_sa):
+    """(a) gradients are also checked RELATIVELY on every entry of at least 1e-3 of the tensor's maximum
+    (tolerance 1e-3), not only against 1e-4 of the maximum; (b) knife-edge pixels keep their upstream gradient: the oracle's
+    backward runs them under the outcome of their near-threshold decisions that the HIP forward took (oracle.backward with
+    pixel_overrides, orc_blend_bwd_pixel) instead of giving them zero gradient."""
+    W, H, P = 320, 240, 20000
+    sc = util.make_scene(P, W, H, seed=33, regime="mapping")
+    oracle.set_threads(os.cpu_count() or 1)
+    o = util.oracle_forward(oracle, sc, use_sa=use_sa)
+    h = util.hip_forward(sc, use_sa=use_sa)
+    stable = (o["stability"] > KNIFE).reshape(H, W)
+    n_knife = int((~stable).sum())
+    assert 0 < n_knife < 2e-3 * W * H, n_knife
+    overrides = util.match_knife_variants(oracle, o, h, stable, IMG_TOL, KNIFE)
+    flipped = sum(1 for _, _, m in overrides if m != 0)
+    print(f"knife-edge pixels with upstream gradient: {n_knife}, of which {flipped} under a flipped decision")
+    dc, da = util.make_upstream_grads(W, H, channels=(0, 1, 2, 3, 4, 5, 6))
+    dc, da = (dc * W * H).numpy(), (da * W * H).numpy()
+    # the knife-edge pixels carry TEN times their share, so a wrong outcome on one of them cannot hide in the noise
+    dc[:, ~stable] *= 10; da[:, ~stable] *= 10
+    go = oracle.backward(o, dc, da, pixel_overrides=overrides, knife=KNIFE)
+    gh = util.hip_backward(h, dc, da)
+    oracle.set_threads(1)
+    for k in ALL_GRADS:
+        ref = go[k].reshape(gh[k].shape)
+        assert util.grad_err(gh[k], ref) <= GRAD_TOL, k
+        assert util.grad_err_mid(gh[k], ref) <= MID_TOL, (k, util.grad_err_mid(gh[k], ref))
+
+
+def test_full_size_default_mode_against_the_oracle(oracle):
+    """the library's DEFAULT mode (footprint binning) at the headline size, 640x480 / 500k, directly
+    against the oracle instead of by transitivity: its lists are ordered subsequences of the oracle's; the oracle's own
+    blend on those lists reproduces the oracle's image, state and gradients bit for bit; and the HIP outputs / gradients match
+    that oracle run (knife-edge pixels resolved against the oracle's decision variants; gradients also entry-wise on the
+    mid-magnitude entries)."""
+    from tests.test_gpu_footprint import _assert_subsequence
+    P, W, H = 500000, 640, 480
+    sc = util.make_scene(P, W, H, seed=0, regime="mapping")
+    oracle.set_threads(os.cpu_count() or 1)
+    o = util.oracle_forward(oracle, sc, use_sa=True)
+    ht = util.hip_forward(sc, use_sa=True, binning="footprint")
+    assert ht["num_rendered"] < 0.9 * o["num_rendered"]
+    np.testing.assert_array_equal(ht["radii"], o["radii"])
+    _assert_subsequence(o, ht, o["ranges"].shape[0])
+    ot = oracle.reblend(o, ht["ranges"], ht["point_list"])
+    for k in ("color", "allmap", "final_T", "median_depth", "depth_std"):  # (n_contrib counts positions in the lists: differs)
+        np.testing.assert_array_equal(ot[k].view(np.uint32), o[k].view(np.uint32), err_msg=k)
+    stable = (ot["stability"] > KNIFE).reshape(H, W)
+    assert (~stable).mean() < 5e-3
+    HW = H * W
+    np.testing.assert_array_equal(ht["last_contributor"][stable], ot["n_contrib"][:HW].reshape(H, W)[stable])
+    np.testing.assert_array_equal(ht["median_contributor"][stable], ot["n_contrib"][HW:].reshape(H, W)[stable])
+    assert np.abs(ht["color"] - ot["color"])[:, stable].max() <= IMG_TOL
+    assert (np.abs(ht["allmap"] - ot["allmap"])[:, stable].max(axis=1) <= IMG_TOL).all()
+    util.check_knife_pixels(oracle, ot, ht, stable, IMG_TOL, KNIFE)
+    dc, da = util.make_upstream_grads(W, H, seed=1, channels=(0, 1, 2, 3, 4, 5, 6))
+    dc, da = (dc * W * H).numpy(), (da * W * H).numpy()
+    dc[:, ~stable] = 0; da[:, ~stable] = 0
+    go, gt = oracle.backward(o, dc, da), oracle.backward(ot, dc, da)
+    gh = util.hip_backward(ht, dc, da)
+    oracle.set_threads(1)
+    for k in ALL_GRADS:
+        np.testing.assert_array_equal(gt[k].view(np.uint32), go[k].view(np.uint32), err_msg=k)
+        ref = go[k].reshape(gh[k].shape)
+        assert util.grad_err(gh[k], ref) <= GRAD_TOL, k
+        assert util.grad_err_mid(gh[k], ref) <= MID_TOL, (k, util.grad_err_mid(gh[k], ref))

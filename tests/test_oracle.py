@@ -239,3 +239,31 @@ def test_batched_pure_pytorch_render_matches_c_oracle(oracle):
         assert np.abs(r["allmap"].detach().numpy() - o["allmap"])[:, stable].max() <= 1e-3
         (r["color"].sum() + r["allmap"][:2].sum()).backward()
         assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in leaves.values())
+
+
+def test_pixel_override_backward_reproduces_the_plain_backward():
+    """oracle.backward(pixel_overrides=...) (orc_blend_bwd_pixel: the backward of one pixel on RECORDED forward outcomes)
+    with no decision flipped must give what the plain backward gives -- for every pixel of a small image, both distortion
+    modes, all ten upstream channels."""
+    from oracle import gs2d_oracle as orc
+    from tests import util
+    W, H, P = 64, 48, 600
+    sc = util.make_scene(P, W, H, seed=9, regime="mapping")
+    for use_sa in (True, False):
+        o = util.oracle_forward(orc, sc, use_sa=use_sa, bg=(0.3, 0.1, 0.6))
+        dc, da = util.make_upstream_grads(W, H, channels=(0, 1, 2, 3, 4, 5, 6))
+        dc, da = (dc * W * H).numpy(), (da * W * H).numpy()
+        g0 = orc.backward(o, dc, da)
+        every = [(x, y, 0) for y in range(H) for x in range(W)]
+        g1 = orc.backward(o, dc, da, pixel_overrides=every, knife=0.0)
+        for k in ("dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dtransMat", "dL_dscales", "dL_drotations", "dL_dmeans2D", "dL_dnormal"):
+            assert np.abs(g0[k]).max() > 0, k
+            assert util.grad_err(g1[k], g0[k]) <= 1e-6, (use_sa, k)
+        # a flipped decision changes the result (the override is not a no-op): pick a pixel with a near-threshold decision
+        ys, xs = np.nonzero((o["stability"] < 5e-2).reshape(H, W))
+        if len(ys):
+            x, y = int(xs[0]), int(ys[0])
+            nk, variants = orc.pixel_variants(o, x, y, 5e-2)
+            assert nk >= 1 and len(variants) >= 2 and variants[1]["mask"] == 1
+            g2 = orc.backward(o, dc, da, pixel_overrides=[(x, y, 1)], knife=5e-2)
+            assert any(util.grad_err(g2[k], g0[k]) > 1e-7 for k in ("dL_dcolors", "dL_dopacity", "dL_dtransMat"))

@@ -132,6 +132,38 @@ def grad_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+def grad_err_mid(a, b, floor=1e-3):
+    """max RELATIVE error over the entries with |b| >= floor * max|b|: constrains the mid-magnitude entries that the
+    per-tensor max-norm of grad_err leaves free (an entry of 1e-3 max may be 10 % off under grad_err <= 1e-4)."""
+    a = np.asarray(a, np.float64).ravel(); b = np.asarray(b, np.float64).ravel()
+    if b.size == 0 or np.abs(b).max() == 0:
+        return 0.0
+    sel = np.abs(b) >= floor * np.abs(b).max()
+    return float((np.abs(a[sel] - b[sel]) / np.abs(b[sel])).max())
+
+
+def match_knife_variants(orc, o, h, stable, tol, knife, scale=None):
+    """For every knife-edge pixel: the outcome of its near-threshold decisions (flip mask of oracle.pixel_variants) under which
+    the oracle's pixel equals the HIP pixel (same contributors, smallest error <= tol).  Returns [(x, y, mask)] -- the input of
+    oracle.backward(pixel_overrides=...), which lets those pixels take part in a gradient comparison."""
+    ys, xs = np.nonzero(~stable)
+    sc = np.ones(7) if scale is None else np.asarray(scale, np.float64)
+    out = []
+    for y, x in zip(ys.tolist(), xs.tolist()):
+        nk, variants = orc.pixel_variants(o, x, y, knife)
+        best = None
+        for v in variants:
+            if v["last_contributor"] != int(h["last_contributor"][y, x]) or v["median_contributor"] != int(h["median_contributor"][y, x]):
+                continue
+            e = max(float(np.abs(h["color"][:, y, x] - v["color"]).max()),
+                    float((np.abs(h["allmap"][:, y, x] - v["others"]) / sc).max()))
+            if best is None or e < best[0]:
+                best = (e, v["mask"])
+        assert best is not None and best[0] <= tol, f"knife-edge pixel ({x},{y}) matches no oracle outcome"
+        out.append((x, y, best[1]))
+    return out
+
+
 def check_knife_pixels(orc, o, h, stable, tol, knife, scale=None):
     """Knife-edge pixels (a discrete decision of the blend within `knife` of its threshold in the oracle) are excluded from
     the plain L-inf comparison because a 1-ulp difference of v_exp_f32 / v_rcp_f32 may flip that decision.  They are not
