@@ -86,6 +86,21 @@ class GradBucket:
 MAX_BATCH_KEYFRAMES = 8  # GS2D_MAX_FRAMES
 
 
+def k_keyframe_schedule(K, reference_steps, reference_lrs):
+    """The optimisation policy for steps that see K keyframes.  The reference takes ONE randomly
+    drawn keyframe per optimizer step (slam/Backend.py:101-128, Adam with eps 1e-15 at scene/Gaussians.py:137); a sharded
+    step takes K and the bucket holds the SUM of their gradients -- under Adam the update does not depend on the scale of
+    the gradient, so sum and mean give the same trajectory (measured: 0.14853 vs 0.14852, profiles/kpolicy_probe_r03.txt)
+    and no division kernel is spent.  To spend the same number of keyframe visits as the reference in 1/K of its steps:
+        steps = ceil(reference_steps / K),  learning rates = reference x K   (linear scaling)
+    which on the synthetic mapping problem of tests/test_gpu_round3.py ends at or below the reference loop's loss for K = 2
+    and 4 (0.372 / 0.354 vs 0.407 of the start loss; sqrt scaling: 0.424; unscaled: 0.494).  Keeping the reference's step
+    count and learning rates instead (K times the visits) is never worse per step (0.361 / 0.326 vs 0.407).
+    Returns (steps, {name: lr})."""
+    K = max(1, int(K))
+    return -(-int(reference_steps) // K), {n: lr * K for n, lr in reference_lrs.items()}
+
+
 def shard_keyframes(keyframes, rank, world_size):
     """Keyframe k of the batch goes to rank k % world_size (independent units, no data-path exchange)."""
     return [kf for i, kf in enumerate(keyframes) if i % world_size == rank]

@@ -424,6 +424,116 @@ int fwd_phase_b(const FwdShared& c, FwdFrame& f, int slot)
     return 0;
 }
 
+// Phases A and B for K frames with every stage batched (tiles <= GS2D_BIN_MAX_TILES, no pose).  Same per-frame results as
+// fwd_phase_a + fwd_phase_b: the kernels' bodies are the single-frame kernels' own.
+int fwd_batch_fused(const FwdShared& c, FwdFrame* f, int K)
+{
+    const int debug = c.debug;
+    hipStream_t s = c.s;
+    const int P = c.P, width = c.width, height = c.height;
+    const GeomLayout GL = geom_layout(P);
+    const ImgLayout IL = img_layout(width, height);
+    gs2d::PreFwdFrames pre;
+    gs2d::BinFrames bin;
+    CamParams cam0;
+    cam0.vm = nullptr; cam0.pm = nullptr; cam0.campos = nullptr;
+    cam0.W = width; cam0.H = height;
+    cam0.gx = (width + GS2D_TILE - 1) / GS2D_TILE;
+    cam0.gy = (height + GS2D_TILE - 1) / GS2D_TILE;
+    cam0.tight = g_reference_binning.load() == 0;
+    if (!g_pinned.p) GS2D_CHECK(hipHostMalloc((void**)&g_pinned.p, 64, hipHostMallocCoherent), "hipHostMalloc");
+    const int nblk = (P + 255) / 256;
+    for (int k = 0; k < K; k++) {
+        if (!f[k].geometry_alloc || !f[k].binning_alloc || !f[k].image_alloc) return fail_msg("allocator callbacks are required");
+        f[k].GL = GL;
+        f[k].geom = (char*)f[k].geometry_alloc(f[k].geometry_user, GL.total);
+        if (!f[k].geom) return fail_msg("geometry allocation failed");
+        g_fwd.drop(f[k].geom);
+        f[k].cam = cam0;
+        f[k].cam.vm = f[k].viewmatrix; f[k].cam.pm = f[k].projmatrix; f[k].cam.campos = f[k].cam_pos;
+        char* geom = f[k].geom;
+        gs2d::PreFwdFrame& q = pre.f[k];
+        q.vm = f[k].viewmatrix; q.pm = f[k].projmatrix; q.campos = f[k].cam_pos;
+        q.radii = f[k].radii; q.depths = (float*)(geom + GL.depths); q.rec = (float4*)(geom + GL.rec);
+        q.tiles_touched = (uint32_t*)(geom + GL.tiles_touched); q.rect = (ushort4*)(geom + GL.rect);
+        q.clamped = (uint8_t*)(geom + GL.clamped); q.block_sums = (uint32_t*)(geom + GL.scan_tmp);
+        gs2d::BinFrame& b = bin.f[k];
+        b.rect = q.rect; b.depths = q.depths; b.tiles_touched = q.tiles_touched; b.block_sums = q.block_sums;
+        b.total_dev = q.block_sums + nblk + 8;
+        f[k].pinned = g_pinned.p + k;
+        *f[k].pinned = 0xFFFFFFFFu;
+        b.total_host = g_pinned.p + k;
+        b.point_offsets = (uint32_t*)(geom + GL.point_offsets);
+        b.R = 0; b.nblocks = 0;
+    }
+    for (int k = K; k < GS2D_MAX_BATCH; k++) { pre.f[k] = pre.f[0]; bin.f[k] = bin.f[0]; }
+    g_timer.begin(ST_PREPROCESS, s);
+    gs2d::launch_preprocess_fwd_batch(P, K, c.D, c.M, c.means3D, c.scales, c.scale_modifier, c.rotations, c.opacities, c.shs,
+                                      c.transMat_precomp, c.colors_precomp, cam0, pre, s);
+    g_timer.end(ST_PREPROCESS, s);
+    GS2D_STAGE("preprocess (batch)");
+    g_timer.begin(ST_SCAN, s);
+    gs2d::launch_offsets_blocksums_batch(P, K, bin, s);
+    g_timer.end(ST_SCAN, s);
+    {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return fail("scan (batch)", le);  // nothing was enqueued: nothing will store into the words
+    }
+    for (int k = 0; k < K; k++) f[k].store_pending = true;
+    // while the GPU works towards the K totals: image chunks and, from the previous call's counts, the binning chunks
+    const bool det = g_deterministic.load() != 0;
+    char* bin_pre[GS2D_MAX_BATCH];
+    size_t pre_bytes[GS2D_MAX_BATCH];
+    for (int k = 0; k < K; k++) {
+        f[k].img = (char*)f[k].image_alloc(f[k].image_user, IL.total);
+        if (!f[k].img) return fail_msg("image allocation failed");
+        LastCount& last = g_last[k];
+        const bool same_shape = last.P == P && last.W == width && last.H == height;
+        const size_t guess_R = same_shape ? (size_t)last.R + last.R / 8 + 4096 : (size_t)P * 3 + 4096;
+        pre_bytes[k] = bin_layout((int)(guess_R > 0x7fffffffull ? 0x7fffffffull : guess_R), det).total;
+        bin_pre[k] = (char*)f[k].binning_alloc(f[k].binning_user, pre_bytes[k]);
+    }
+    const int tile_bits = (int)higher_msb((uint32_t)(cam0.gx * cam0.gy));
+    for (int k = 0; k < K; k++) {
+        if (!wait_total(f[k], s)) return fail_msg("num_rendered read-back failed");
+        const uint32_t num_rendered_u = *f[k].pinned;
+        if (num_rendered_u == 0xFFFFFFFFu) return fail_msg("num_rendered read-back failed");
+        if (num_rendered_u > 0x7fffffffu) return fail_msg("num_rendered overflows int32");
+        const int R = (int)num_rendered_u;
+        f[k].R = R;
+        LastCount& last = g_last[k];
+        last.P = P; last.W = width; last.H = height; last.R = num_rendered_u;
+        const BinLayout BL = bin_layout(R, det);
+        const bool reuse_pre = bin_pre[k] && BL.total <= pre_bytes[k];
+        char* bn = reuse_pre ? bin_pre[k] : (char*)f[k].binning_alloc(f[k].binning_user, BL.total);
+        if (!bn) return fail_msg("binning allocation failed");
+        f[k].bin = bn;
+        f[k].bin_bytes = reuse_pre ? pre_bytes[k] : BL.total;
+        gs2d::BinFrame& b = bin.f[k];
+        b.R = R;
+        b.point_list = (uint32_t*)(bn + BL.point_list);
+        b.keys = (uint64_t*)(bn + BL.keys);
+        b.vals_alt = (uint32_t*)(bn + BL.vals_alt);
+        b.keys_alt = (uint64_t*)(bn + BL.keys_alt);
+        // one counting-sort pass: the unsorted pairs start in the "alt" buffers so that the result lands in (keys, point_list)
+        b.keys_unsorted = b.keys_alt; b.vals_unsorted = b.vals_alt;
+        b.hist = (uint32_t*)(bn + BL.hist);
+        b.ranges = (uint2*)(f[k].img + IL.ranges);
+        gs2d::BlendFwdFrame& o = f[k].bf;
+        o.ranges = b.ranges; o.point_list = b.point_list; o.rec = (const float4*)(f[k].geom + GL.rec);
+        o.out_color = f[k].out_color; o.out_others = f[k].out_others; o.pix_state = (float*)(f[k].img + IL.pix);
+        o.hits = (uint8_t*)(bn + BL.hits); o.hits4 = (uint8_t*)(bn + BL.hits4);
+        o.zero = (float4*)(f[k].geom + GL.grad_rec);
+    }
+    if (debug) GS2D_CHECK(hipStreamSynchronize(s), "scan (batch)");
+    for (int k = K; k < GS2D_MAX_BATCH; k++) bin.f[k] = bin.f[0];
+    g_timer.begin(ST_SORT, s);
+    gs2d::launch_bin_sort_batch(P, K, IL.tiles, cam0.gx, tile_bits, bin, debug ? 1 : 0, s);
+    g_timer.end(ST_SORT, s);
+    GS2D_STAGE("duplicate + sort (batch)");
+    return 0;
+}
+
 int fwd_phase_c(const FwdShared& c, FwdFrame* frames, int K)
 {
     const int debug = c.debug;
@@ -508,12 +618,19 @@ int gs2d_forward_batch(int K, const gs2d_frame_io* io, int P, int D, int M, cons
         f[k].out_color = io[k].out_color; f[k].out_others = io[k].out_others; f[k].radii = io[k].radii;
     }
     auto drain = [&]() { for (int k = 0; k < K; k++) (void)wait_total(f[k], c.s); };
-    // all K preprocess + scan pairs are enqueued before the host looks at the first total: by the time frame 0's chunks
-    // have been requested, the later frames' totals are already on their way
-    for (int k = 0; k < K; k++)
-        if (fwd_phase_a(c, f[k], k) < 0) { drain(); return -1; }
-    for (int k = 0; k < K; k++)
-        if (fwd_phase_b(c, f[k], k) < 0) { drain(); return -1; }
+    if (img_layout(width, height).tiles <= GS2D_BIN_MAX_TILES) {
+        // every stage as ONE launch over the K frames (blockIdx.y = frame): 8 launches instead of 7 K + 1, and the
+        // latency-bound stages (block-sum scan, tile histogram, row scan, scatter, per-tile depth sort) get K times the
+        // workgroups for the same latency
+        if (fwd_batch_fused(c, f, K) < 0) { drain(); return -1; }
+    } else {
+        // more tiles than the single-pass binning takes: frame by frame through the generic radix passes; all K preprocess +
+        // scan pairs are still enqueued before the host looks at the first total
+        for (int k = 0; k < K; k++)
+            if (fwd_phase_a(c, f[k], k) < 0) { drain(); return -1; }
+        for (int k = 0; k < K; k++)
+            if (fwd_phase_b(c, f[k], k) < 0) { drain(); return -1; }
+    }
     if (fwd_phase_c(c, f, K) < 0) return -1;
     for (int k = 0; k < K; k++) num_rendered[k] = f[k].R;
     return 0;
@@ -700,16 +817,29 @@ int gs2d_backward_batch(int K, const gs2d_frame_grad* fr, int P, int D, int M, c
         g_timer.end(ST_BLEND_BWD, s);
         GS2D_STAGE("blend_bwd (batch)");
     }
-    for (int k = 0; k < K; k++) {  // the per-Gaussian stage, frame by frame (each frame has its own outputs)
-        const gs2d_frame_grad& f = fr[k];
-        const int rc = gs2d_backward_staged(GS2D_BWD_PREPROCESS, 0, P, P, D, M, f.num_rendered, background, width, height, means3D, shs,
-                                            colors_precomp, scales, scale_modifier, rotations, transMat_precomp, f.viewmatrix,
-                                            f.projmatrix, f.campos, f.tan_fovx, f.tan_fovy, f.radii, f.geom_buffer, f.binning_buffer,
-                                            f.img_buffer, f.dL_dpix, f.dL_depths, f.dL_dmean2D, f.dL_dnormal, f.dL_dopacity,
-                                            f.dL_dcolor, f.dL_dmean3D, f.dL_dtransMat, f.dL_dsh, f.dL_dscale, f.dL_drot, use_sa, debug,
-                                            nullptr, nullptr, nullptr, stream);
-        if (rc < 0) return rc;
+    {   // the per-Gaussian stage of all frames in one launch (each frame has its own outputs)
+        gs2d::PreBwdFrames tab;
+        for (int k = 0; k < K; k++) {
+            const gs2d_frame_grad& f = fr[k];
+            if (!f.dL_dmean2D || !f.dL_dopacity || !f.dL_dcolor || !f.dL_dmean3D || !f.dL_dscale || !f.dL_drot)
+                return fail_msg("per-Gaussian gradient outputs are required for every frame of a batch");
+            gs2d::PreBwdFrame& q = tab.f[k];
+            q.vm = f.viewmatrix; q.pm = f.projmatrix; q.campos = f.campos;
+            // rasterizer_impl.cu:396-397 + backward.cu:641-642: the backward rebuilds W,H from focal*tan in float32
+            const float focal_y = height / (2.0f * f.tan_fovy), focal_x = width / (2.0f * f.tan_fovx);
+            q.W = (int)(focal_x * f.tan_fovx * 2); q.H = (int)(focal_y * f.tan_fovy * 2);
+            q.rec = (const float4*)(f.geom_buffer + GL.rec); q.radii = f.radii;
+            q.clamped = (const uint8_t*)(f.geom_buffer + GL.clamped); q.grad_rec = (const float*)(f.geom_buffer + GL.grad_rec);
+            q.dL_dtransMat = f.dL_dtransMat; q.dL_dnormal = f.dL_dnormal; q.dL_dcolor = f.dL_dcolor; q.dL_dopacity = f.dL_dopacity;
+            q.dL_dsh = f.dL_dsh; q.dL_dmean2D = f.dL_dmean2D; q.dL_dmean3D = f.dL_dmean3D; q.dL_dscale = f.dL_dscale; q.dL_drot = f.dL_drot;
+        }
+        for (int k = K; k < GS2D_MAX_BATCH; k++) tab.f[k] = tab.f[0];
+        g_timer.begin(ST_PREPROCESS_BWD, s);
+        gs2d::launch_preprocess_bwd_batch(P, K, D, M, means3D, shs, scales, rotations, /*need_record=*/scale_modifier != 1.0f, tab, s);
+        g_timer.end(ST_PREPROCESS_BWD, s);
+        GS2D_STAGE("preprocess_bwd (batch)");
     }
+    (void)colors_precomp; (void)transMat_precomp;
     return 0;
 }
 

@@ -59,8 +59,8 @@ __global__ void __launch_bounds__(SCAN_T) scan_reduce_kernel(const uint32_t* __r
 // consecutive sums [i K, (i+1) K): one round of loads, one workgroup scan of the 256 partial sums, one round of stores
 // (the chunk-by-chunk loop this replaces paid a load -> scan -> store -> barrier chain per 256 sums: 6.5 us for the 1954
 // sums of 500k Gaussians, on the path to the host's num_rendered).
-__global__ void __launch_bounds__(SCAN_T) scan_blocksums_kernel(uint32_t* __restrict__ block_sums, int nblocks, uint32_t* __restrict__ total_out,
-                                                                uint32_t* __restrict__ total_host)
+__device__ __forceinline__ void scan_blocksums_body(uint32_t* __restrict__ block_sums, int nblocks, uint32_t* __restrict__ total_out,
+                                                    uint32_t* __restrict__ total_host)
 {
     const int K = (nblocks + SCAN_T - 1) / SCAN_T;
     const int i0 = min(nblocks, (int)threadIdx.x * K), i1 = min(nblocks, i0 + K);
@@ -79,6 +79,18 @@ __global__ void __launch_bounds__(SCAN_T) scan_blocksums_kernel(uint32_t* __rest
     for (int j = 0; j < KR; j++)
         if (i0 + j < i1) { block_sums[i0 + j] = running; running += v[j]; }
     for (int i = i0 + KR; i < i1; i++) { const uint32_t x = block_sums[i]; block_sums[i] = running; running += x; }
+}
+__global__ void __launch_bounds__(SCAN_T) scan_blocksums_kernel(uint32_t* __restrict__ block_sums, int nblocks, uint32_t* __restrict__ total_out,
+                                                                uint32_t* __restrict__ total_host)
+{
+    scan_blocksums_body(block_sums, nblocks, total_out, total_host);
+}
+// Batched forms (gs2d_forward_batch): blockIdx.y = frame, per-frame pointers from a by-value table in the kernel arguments;
+// the bodies are the single-frame kernels' own.
+__global__ void __launch_bounds__(SCAN_T) scan_blocksums_batch_kernel(int nblocks, const gs2d::BinFrames tab)
+{
+    const gs2d::BinFrame& f = tab.f[blockIdx.y];
+    scan_blocksums_body(f.block_sums, nblocks, f.total_dev, f.total_host);
 }
 
 __global__ void __launch_bounds__(SCAN_T) scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n,
@@ -112,10 +124,10 @@ __device__ __forceinline__ int f2i_sat(float v)
 
 // rasterizer_impl.cu:70-111; one thread per Gaussian, tiles emitted row-major (y outer, x inner).  The rectangle comes
 // from the preprocess kernel (the reference's, or its intersection with the footprint bound), not re-derived from radii.
-__global__ void __launch_bounds__(256)
-duplicate_kernel(int P, const ushort4* __restrict__ rect, const float* __restrict__ depths,
-                 const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_offsets,
-                 uint32_t* __restrict__ point_offsets, int gx, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+__device__ __forceinline__ void
+duplicate_body(int P, const ushort4* __restrict__ rect, const float* __restrict__ depths,
+               const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_offsets,
+               uint32_t* __restrict__ point_offsets, int gx, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     // The prefix sum of tiles_touched (rasterizer_impl.cu:283) is finished here: the preprocess kernel left one sum per
     // 256 Gaussians, scan_blocksums_kernel turned those into exclusive block offsets, and this workgroup (the same 256
@@ -138,6 +150,18 @@ duplicate_kernel(int P, const ushort4* __restrict__ rect, const float* __restric
             vals[off] = (uint32_t)idx;
             off++;
         }
+}
+__global__ void __launch_bounds__(256)
+duplicate_kernel(int P, const ushort4* __restrict__ rect, const float* __restrict__ depths,
+                 const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_offsets,
+                 uint32_t* __restrict__ point_offsets, int gx, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    duplicate_body(P, rect, depths, tiles_touched, block_offsets, point_offsets, gx, keys, vals);
+}
+__global__ void __launch_bounds__(256) duplicate_batch_kernel(int P, int gx, const gs2d::BinFrames tab)
+{
+    const gs2d::BinFrame& f = tab.f[blockIdx.y];
+    duplicate_body(P, f.rect, f.depths, f.tiles_touched, f.block_sums, f.point_offsets, gx, f.keys_unsorted, f.vals_unsorted);
 }
 
 // ---------------------------------------------------------------- radix sort pass (8-bit digit)
@@ -239,8 +263,8 @@ constexpr int BIN_ITEMS = GS2D_BIN_ITEMS;   // instances per workgroup
 constexpr int BIN_WAVE_ITEMS = BIN_ITEMS / 4;
 
 // hist[tile * nblocks + block]
-__global__ void __launch_bounds__(BIN_T)
-bin_hist_kernel(const uint64_t* __restrict__ keys, int n, int ntiles, uint32_t* __restrict__ hist, int nblocks)
+__device__ __forceinline__ void
+bin_hist_body(const uint64_t* __restrict__ keys, int n, int ntiles, uint32_t* __restrict__ hist, int nblocks)
 {
     extern __shared__ uint32_t lds[];  // [ntiles]
     for (int t = threadIdx.x; t < ntiles; t += BIN_T) lds[t] = 0;
@@ -260,10 +284,21 @@ bin_hist_kernel(const uint64_t* __restrict__ keys, int n, int ntiles, uint32_t* 
     __syncthreads();
     for (int t = threadIdx.x; t < ntiles; t += BIN_T) hist[(size_t)t * nblocks + blockIdx.x] = lds[t];
 }
+__global__ void __launch_bounds__(BIN_T)
+bin_hist_kernel(const uint64_t* __restrict__ keys, int n, int ntiles, uint32_t* __restrict__ hist, int nblocks)
+{
+    bin_hist_body(keys, n, ntiles, hist, nblocks);
+}
+__global__ void __launch_bounds__(BIN_T) bin_hist_batch_kernel(int ntiles, const gs2d::BinFrames tab)
+{
+    const gs2d::BinFrame& f = tab.f[blockIdx.y];
+    if ((int)blockIdx.x >= f.nblocks) return;  // the grid is sized for the frame with the most instances
+    bin_hist_body(f.keys_unsorted, f.R, ntiles, f.hist, f.nblocks);
+}
 
 // hist[tile][0..nblocks) -> exclusive scan along the blocks, in place; tile_total[tile] = the row's sum.  One wave per tile.
-__global__ void __launch_bounds__(256)
-bin_row_scan_kernel(uint32_t* __restrict__ hist, int ntiles, int nblocks, uint32_t* __restrict__ tile_total)
+__device__ __forceinline__ void
+bin_row_scan_body(uint32_t* __restrict__ hist, int ntiles, int nblocks, uint32_t* __restrict__ tile_total)
 {
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (tile >= ntiles) return;
@@ -278,14 +313,24 @@ bin_row_scan_kernel(uint32_t* __restrict__ hist, int ntiles, int nblocks, uint32
     }
     if (lane == 0) tile_total[tile] = carry;
 }
+__global__ void __launch_bounds__(256)
+bin_row_scan_kernel(uint32_t* __restrict__ hist, int ntiles, int nblocks, uint32_t* __restrict__ tile_total)
+{
+    bin_row_scan_body(hist, ntiles, nblocks, tile_total);
+}
+__global__ void __launch_bounds__(256) bin_row_scan_batch_kernel(int ntiles, const gs2d::BinFrames tab)
+{
+    const gs2d::BinFrame& f = tab.f[blockIdx.y];
+    if (f.nblocks > 0) bin_row_scan_body(f.hist, ntiles, f.nblocks, f.hist + (size_t)ntiles * f.nblocks);
+}
 
 // offs_excl[tile][block] = instances of the tile in earlier blocks (bin_row_scan_kernel), tile_total[tile] = all of them.
 // Stable: element order inside a tile is preserved.
 // Output: packed (depth bits, id) pairs in keys_out's 8-byte slots (vals_out is not written).
-__global__ void __launch_bounds__(BIN_T)
-bin_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
-                   uint32_t* __restrict__ vals_out, int n, int ntiles, int nbits, const uint32_t* __restrict__ offs_excl,
-                   const uint32_t* __restrict__ tile_total, int nblocks, uint2* __restrict__ ranges)
+__device__ __forceinline__ void
+bin_scatter_body(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
+                 uint32_t* __restrict__ vals_out, int n, int ntiles, int nbits, const uint32_t* __restrict__ offs_excl,
+                 const uint32_t* __restrict__ tile_total, int nblocks, uint2* __restrict__ ranges)
 {
     extern __shared__ uint32_t lds[];  // [4][ntiles] per-wave counts, then running destinations
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -349,6 +394,20 @@ bin_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restr
         }
     }
 }
+__global__ void __launch_bounds__(BIN_T)
+bin_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
+                   uint32_t* __restrict__ vals_out, int n, int ntiles, int nbits, const uint32_t* __restrict__ offs_excl,
+                   const uint32_t* __restrict__ tile_total, int nblocks, uint2* __restrict__ ranges)
+{
+    bin_scatter_body(keys_in, vals_in, keys_out, vals_out, n, ntiles, nbits, offs_excl, tile_total, nblocks, ranges);
+}
+__global__ void __launch_bounds__(BIN_T) bin_scatter_batch_kernel(int ntiles, int nbits, const gs2d::BinFrames tab)
+{
+    const gs2d::BinFrame& f = tab.f[blockIdx.y];
+    if ((int)blockIdx.x >= f.nblocks) return;
+    bin_scatter_body(f.keys_unsorted, f.vals_unsorted, f.keys, f.point_list, f.R, ntiles, nbits, f.hist,
+                     f.hist + (size_t)ntiles * f.nblocks, f.nblocks, f.ranges);
+}
 
 // ---------------------------------------------------------------- per-tile depth sort (LDS)
 // After the global passes have binned the pairs by tile id (stable, so each tile's segment is still in Gaussian
@@ -409,9 +468,9 @@ __device__ void sort_segment_by_depth(uint32_t* ka, uint32_t* va, uint32_t* kb, 
 // packed != 0: the segment holds (depth bits, id) pairs in the 8-byte key slots (output of bin_scatter_kernel);
 // packed == 0: 64-bit keys + separate ids (output of the generic radix passes).  The sorted ids always land in `vals`
 // (the point list); the full 64-bit keys are materialised only when write_keys != 0 (debug / parity tests).
-__global__ void __launch_bounds__(256)
-tile_depth_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                       uint64_t* __restrict__ keys_alt, uint32_t* __restrict__ vals_alt, int cap, int packed, int write_keys)
+__device__ __forceinline__ void
+tile_depth_sort_body(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                     uint64_t* __restrict__ keys_alt, uint32_t* __restrict__ vals_alt, int cap, int packed, int write_keys)
 {
     extern __shared__ uint32_t dyn[];  // [4][cap]: ka, va, kb, vb
     __shared__ uint32_t wcnt[4][256];
@@ -455,6 +514,17 @@ tile_depth_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ 
             if (write_keys) kseg[i] = hi | ka[i];
         }
     }
+}
+__global__ void __launch_bounds__(256)
+tile_depth_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                       uint64_t* __restrict__ keys_alt, uint32_t* __restrict__ vals_alt, int cap, int packed, int write_keys)
+{
+    tile_depth_sort_body(ranges, keys, vals, keys_alt, vals_alt, cap, packed, write_keys);
+}
+__global__ void __launch_bounds__(256) tile_depth_sort_batch_kernel(int cap, int write_keys, const gs2d::BinFrames tab)
+{
+    const gs2d::BinFrame& f = tab.f[blockIdx.y];
+    if (f.R > 0) tile_depth_sort_body(f.ranges, f.keys, f.point_list, f.keys_alt, f.vals_alt, cap, 1, write_keys);
 }
 
 // rasterizer_impl.cu:116-138
@@ -546,6 +616,32 @@ void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* key
     const int cap = want <= 1536 ? 1536 : (want <= 2048 ? 2048 : (want <= 3072 ? 3072 : 4096));
     hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(tiles), dim3(256), (size_t)cap * 16, s, ranges, keys, vals, keys_alt,
                        vals_alt, cap, packed, write_keys);
+}
+
+void launch_offsets_blocksums_batch(int P, int K, const BinFrames& tab, hipStream_t s)
+{
+    hipLaunchKernelGGL(scan_blocksums_batch_kernel, dim3(1, K), dim3(SCAN_T), 0, s, (P + 255) / 256, tab);
+}
+
+// duplicate + the single-pass tile binning + the per-tile depth sort for K frames, five launches in all (tiles <= GS2D_BIN_MAX_TILES)
+void launch_bin_sort_batch(int P, int K, int tiles, int gx, int nbits, BinFrames& tab, int write_keys, hipStream_t s)
+{
+    int max_blocks = 0;
+    long long max_R = 0;
+    for (int k = 0; k < K; k++) {
+        tab.f[k].nblocks = (tab.f[k].R + BIN_ITEMS - 1) / BIN_ITEMS;
+        max_blocks = tab.f[k].nblocks > max_blocks ? tab.f[k].nblocks : max_blocks;
+        max_R = tab.f[k].R > max_R ? tab.f[k].R : max_R;
+        if (tab.f[k].R == 0) (void)hipMemsetAsync(tab.f[k].ranges, 0, sizeof(uint2) * (size_t)tiles, s);  // nothing will write them
+    }
+    hipLaunchKernelGGL(duplicate_batch_kernel, dim3((P + 255) / 256, K), dim3(256), 0, s, P, gx, tab);
+    if (max_blocks == 0) return;
+    hipLaunchKernelGGL(bin_hist_batch_kernel, dim3(max_blocks, K), dim3(BIN_T), (size_t)tiles * 4, s, tiles, tab);
+    hipLaunchKernelGGL(bin_row_scan_batch_kernel, dim3((tiles + 3) / 4, K), dim3(256), 0, s, tiles, tab);
+    hipLaunchKernelGGL(bin_scatter_batch_kernel, dim3(max_blocks, K), dim3(BIN_T), (size_t)tiles * 16, s, tiles, nbits, tab);
+    const int want = (int)((max_R * 13) / ((long long)tiles * 10));  // (launch_tile_depth_sort's rule, on the longest frame)
+    const int cap = want <= 1536 ? 1536 : (want <= 2048 ? 2048 : (want <= 3072 ? 3072 : 4096));
+    hipLaunchKernelGGL(tile_depth_sort_batch_kernel, dim3(tiles, K), dim3(256), (size_t)cap * 16, s, cap, write_keys, tab);
 }
 
 void launch_tile_ranges(int R, const uint64_t* keys, uint2* ranges, int tiles, hipStream_t s)

@@ -209,6 +209,42 @@ bool launch_bin_by_tile(int R, int tiles, int nbits, const uint64_t* keys_in, co
 void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt,
                             uint32_t* vals_alt, int packed, int write_keys, hipStream_t s);
 void launch_tile_ranges(int R, const uint64_t* keys, uint2* ranges, int tiles, hipStream_t s);
+// Per-frame pointers of the per-Gaussian kernels in the batched calls (frames share the Gaussian SoA and the image size).
+struct PreFwdFrame {
+    const float *vm, *pm, *campos;
+    int* radii; float* depths; float4* rec; uint32_t* tiles_touched; ushort4* rect; uint8_t* clamped; uint32_t* block_sums;
+};
+struct PreFwdFrames { PreFwdFrame f[8]; };
+struct PreBwdFrame {
+    const float *vm, *pm, *campos;
+    int W, H;                      // rebuilt from focal * tan as the reference does (backward.cu:641-642)
+    const float4* rec; const int* radii; const uint8_t* clamped; const float* grad_rec;
+    float *dL_dtransMat, *dL_dnormal, *dL_dcolor, *dL_dopacity, *dL_dsh, *dL_dmean2D, *dL_dmean3D, *dL_dscale, *dL_drot;
+};
+struct PreBwdFrames { PreBwdFrame f[8]; };
+void launch_preprocess_fwd_batch(int P, int K, int D, int M, const float* means3D, const float* scales, float scale_modifier,
+                                 const float* rotations, const float* opacities, const float* shs, const float* transMat_precomp,
+                                 const float* colors_precomp, const CamParams& cam0, const PreFwdFrames& tab, hipStream_t s);
+void launch_preprocess_bwd_batch(int P, int K, int D, int M, const float* means3D, const float* shs, const float* scales,
+                                 const float* rotations, int need_record, const PreBwdFrames& tab, hipStream_t s);
+
+// Per-frame pointers of the binning chain (duplicate, tile binning, depth sort) in the batched forward.
+struct BinFrame {
+    const ushort4* rect; const float* depths; const uint32_t* tiles_touched;
+    uint32_t* block_sums;      // per-256-Gaussian sums of tiles_touched -> exclusive block offsets (scan_blocksums)
+    uint32_t* total_dev; uint32_t* total_host;
+    uint32_t* point_offsets;
+    uint64_t* keys_unsorted; uint32_t* vals_unsorted;   // duplicate's output
+    uint64_t* keys; uint32_t* point_list;                // binned (packed pairs) -> sorted ids
+    uint64_t* keys_alt; uint32_t* vals_alt;
+    uint32_t* hist;            // tiles x nblocks counters, the tile totals behind them
+    uint2* ranges;
+    int R, nblocks;
+};
+struct BinFrames { BinFrame f[8]; };
+void launch_offsets_blocksums_batch(int P, int K, const BinFrames& tab, hipStream_t s);
+void launch_bin_sort_batch(int P, int K, int tiles, int gx, int nbits, BinFrames& tab, int write_keys, hipStream_t s);
+
 // Per-frame pointers of the blend kernels.  A launch handles K frames of the same size over the same Gaussians (K = 1: the
 // plain call; K > 1: gs2d_forward_batch / gs2d_backward_batch, one grid over K x tiles).
 #define GS2D_MAX_BATCH 8

@@ -171,8 +171,8 @@ __global__ void pose_quat_kernel(const float* __restrict__ Rt, float* __restrict
     for (int i = 0; i < 4; i++) q_out[i] = neg ? -q[i] : q[i];
 }
 
-__global__ void __launch_bounds__(256)
-preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
+__device__ __forceinline__ void
+preprocess_fwd_body(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
                       float scale_modifier, const float* __restrict__ rotations, const float* __restrict__ opacities,
                       const float* __restrict__ shs, const float* __restrict__ transMat_precomp,
                       const float* __restrict__ colors_precomp, const CamParams cam, int* __restrict__ radii,
@@ -304,6 +304,33 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     if ((threadIdx.x & 63) == 0) wave_tiles[threadIdx.x >> 6] = tsum;
     __syncthreads();
     if (threadIdx.x == 0) block_sums[blockIdx.x] = (wave_tiles[0] + wave_tiles[1]) + (wave_tiles[2] + wave_tiles[3]);
+}
+
+__global__ void __launch_bounds__(256)
+preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
+                      float scale_modifier, const float* __restrict__ rotations, const float* __restrict__ opacities,
+                      const float* __restrict__ shs, const float* __restrict__ transMat_precomp,
+                      const float* __restrict__ colors_precomp, const CamParams cam, int* __restrict__ radii,
+                      float* __restrict__ depths, float4* __restrict__ rec, uint32_t* __restrict__ tiles_touched,
+                      ushort4* __restrict__ rect, uint8_t* __restrict__ clamped, const float* __restrict__ pose_Rt,
+                      const float* __restrict__ pose_q, uint32_t* __restrict__ block_sums)
+{
+    preprocess_fwd_body(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, transMat_precomp, colors_precomp, cam,
+                        radii, depths, rec, tiles_touched, rect, clamped, pose_Rt, pose_q, block_sums);
+}
+
+// Batched form (gs2d_forward_batch): blockIdx.y = frame; the Gaussians are shared, camera and outputs come from a by-value table
+__global__ void __launch_bounds__(256)
+preprocess_fwd_batch_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
+                            float scale_modifier, const float* __restrict__ rotations, const float* __restrict__ opacities,
+                            const float* __restrict__ shs, const float* __restrict__ transMat_precomp,
+                            const float* __restrict__ colors_precomp, const CamParams cam0, const gs2d::PreFwdFrames tab)
+{
+    const gs2d::PreFwdFrame& f = tab.f[blockIdx.y];
+    CamParams cam = cam0;
+    cam.vm = f.vm; cam.pm = f.pm; cam.campos = f.campos;
+    preprocess_fwd_body(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, transMat_precomp, colors_precomp, cam,
+                        f.radii, f.depths, f.rec, f.tiles_touched, f.rect, f.clamped, nullptr, nullptr, f.block_sums);
 }
 
 // backward.cu:20-139
@@ -599,6 +626,23 @@ preprocess_bwd_kernel(int first, int P, int D, int M, const float* __restrict__ 
     }
 }
 
+// Batched form (gs2d_backward_batch): blockIdx.y = frame.  No pose, no deterministic variant.
+__global__ void __launch_bounds__(256)
+preprocess_bwd_batch_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+                            const float* __restrict__ scales, const float* __restrict__ rotations, int use_rec,
+                            const gs2d::PreBwdFrames tab)
+{
+    const gs2d::PreBwdFrame& f = tab.f[blockIdx.y];
+    CamParams cam;
+    cam.vm = f.vm; cam.pm = f.pm; cam.campos = f.campos; cam.W = f.W; cam.H = f.H; cam.gx = 0; cam.gy = 0; cam.tight = 0;
+    float pg[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // (pose sums: unused without a pose)
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < P)
+        preprocess_bwd_one(idx, P, D, M, means3D, use_rec ? f.rec : nullptr, f.radii, shs, f.clamped, scales, rotations, cam, f.grad_rec,
+                           f.dL_dtransMat, f.dL_dnormal, f.dL_dcolor, f.dL_dopacity, f.dL_dsh, f.dL_dmean2D, f.dL_dmean3D, f.dL_dscale,
+                           f.dL_drot, nullptr, nullptr, pg);
+}
+
 // Deterministic pose gradient: dL_dpose[c] += sum over the workgroups' partials, always in the same order (lane l adds
 // partials l, l + 64, ... one after the other, then a fixed butterfly over the 64 lanes).
 __global__ void __launch_bounds__(64) pose_reduce_kernel(int n, const float* __restrict__ partials, float* __restrict__ dL_dpose)
@@ -637,6 +681,24 @@ void launch_preprocess_fwd(int P, int D, int M, const float* means3D, const floa
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, transMat_precomp, colors_precomp, cam, radii, depths,
                        rec, tiles_touched, rect, clamped, pose_Rt, pose_q, block_sums);
+}
+
+void launch_preprocess_fwd_batch(int P, int K, int D, int M, const float* means3D, const float* scales, float scale_modifier,
+                                 const float* rotations, const float* opacities, const float* shs, const float* transMat_precomp,
+                                 const float* colors_precomp, const CamParams& cam0, const PreFwdFrames& tab, hipStream_t s)
+{
+    hipLaunchKernelGGL(preprocess_fwd_batch_kernel, dim3((P + 255) / 256, K), dim3(256), 0, s, P, D, M, means3D, scales, scale_modifier,
+                       rotations, opacities, shs, transMat_precomp, colors_precomp, cam0, tab);
+}
+
+void launch_preprocess_bwd_batch(int P, int K, int D, int M, const float* means3D, const float* shs, const float* scales,
+                                 const float* rotations, int need_record, const PreBwdFrames& tab, hipStream_t s)
+{
+    if (P <= 0) return;
+    // (rec is read only when Tw.z cannot be recomputed: precomputed transforms or scale_modifier != 1, see launch_preprocess_bwd)
+    const int use_rec = (scales == nullptr || need_record) ? 1 : 0;
+    hipLaunchKernelGGL(preprocess_bwd_batch_kernel, dim3((P + 255) / 256, K), dim3(256), 0, s, P, D, M, means3D, shs, scales, rotations,
+                       use_rec, tab);
 }
 
 void launch_preprocess_bwd(int first, int P, int D, int M, const float* means3D, const float4* rec, const int* radii,
