@@ -54,11 +54,13 @@ def stage_bytes(P, R, HW):
         "preprocess": 52 * P + 92 * P,         # SoA in; 80-B record + depth/radius/tiles out
         "scan": 8 * P,
         "duplicate": 20 * P + 12 * R,
-        "sort": 24 * R,                        # one read + one write of the 12-B pairs (a 6-pass LSD sort moves 6x)
+        "sort": 24 * R,                        # tile binning: one read + one write of the 12-B pairs (hist + row scan + scatter); the
+                                               # per-tile depth sort runs inside blend_fwd when the lists fit its LDS (round 3)
         "ranges": 8 * R,
         "cull": 0,                             # (runs inside blend_fwd since round 2: id + 52 B of the record in, 4 B out)
-        "blend_fwd": 68 * R + 84 * R + 68 * HW,  # cull phase (id + 52 B of the record in, 8 + 4 B of bits out) + 4-B id + 80-B
-                                               # record per instance; 40 B images + 28 B state per pixel
+        "blend_fwd": 12 * R + 68 * R + 84 * R + 68 * HW,  # depth-sort phase (8-B pair in, 4-B id out) + cull phase (id + 52 B of the
+                                               # record in, 8 + 4 B of bits out) + 4-B id + 80-B record per instance; 40 B images +
+                                               # 28 B state per pixel
         "blend_bwd": 84 * R + 68 * HW + 72 * P,  # gather + per-pixel grads/state + accumulator write-back
         "preprocess_bwd": 152 * P + 80 * P,
     }

@@ -12,7 +12,7 @@ EXPORTS = ["gs2d_forward", "gs2d_backward", "gs2d_forward_posed", "gs2d_backward
            "gs2d_image_layout", "gs2d_last_error", "gs2d_build_info", "gs2d_stage_timing_enable",
            "gs2d_stage_timing_read", "gs2d_slam_loss", "gs2d_adam_step", "gs2d_pose_quat", "gs2d_backward_staged", "gs2d_set_deterministic",
            "gs2d_get_deterministic", "gs2d_set_reference_binning", "gs2d_get_reference_binning", "gs2d_forward_batch",
-           "gs2d_backward_batch"]
+           "gs2d_backward_batch", "gs2d_stage_timing_read_abs"]
 MAX_FRAMES = 8  # GS2D_MAX_FRAMES
 
 
@@ -67,7 +67,7 @@ def lib():
     L.gs2d_forward_batch.argtypes = [i, C.POINTER(FrameIO), i, i, i, vp, i, i, vp, vp, vp, vp, vp, f, vp, vp, i, i,
                                      C.POINTER(C.c_int), vp]
     L.gs2d_backward_batch.restype = i
-    L.gs2d_backward_batch.argtypes = [i, C.POINTER(FrameGrad), i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, i, i, vp]
+    L.gs2d_backward_batch.argtypes = [i, C.POINTER(FrameGrad), i, i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, i, i, vp]
     L.gs2d_pose_quat.restype = i
     L.gs2d_pose_quat.argtypes = [vp, vp, vp]
     L.gs2d_mark_visible.restype = i
@@ -93,6 +93,8 @@ def lib():
     L.gs2d_stage_timing_enable.argtypes = [i]
     L.gs2d_stage_timing_read.restype = i
     L.gs2d_stage_timing_read.argtypes = [C.POINTER(C.c_float)]
+    L.gs2d_stage_timing_read_abs.restype = i
+    L.gs2d_stage_timing_read_abs.argtypes = [C.POINTER(C.c_float)]
     L.gs2d_last_error.restype = C.c_char_p
     L.gs2d_build_info.restype = C.c_char_p
     _lib = L

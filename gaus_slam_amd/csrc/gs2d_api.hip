@@ -181,6 +181,29 @@ int gs2d_stage_timing_read(float ms[9])
     return 0;
 }
 
+// begin / end of every recorded stage in ms relative to the begin of the most recent preprocess stage (-1: not recorded): where
+// the stream sat idle between stages (host reaction to num_rendered, the caller's work between forward and backward ...)
+int gs2d_stage_timing_read_abs(float ms[18])
+{
+    for (int i = 0; i < 2 * ST_COUNT; i++) ms[i] = -1.f;
+    if (!g_timer.recorded[ST_PREPROCESS]) return 0;
+    for (int i = 0; i < ST_COUNT; i++) {
+        if (!g_timer.recorded[i]) continue;
+        if (hipEventSynchronize(g_timer.ev[i][1]) != hipSuccess) return -1;
+        for (int e = 0; e < 2; e++) {
+            float t = 0.f;
+            // (a stage recorded before the base event gives a negative offset: the backward of the PREVIOUS step when called
+            // right after a forward)
+            if (hipEventElapsedTime(&t, g_timer.ev[ST_PREPROCESS][0], g_timer.ev[i][e]) != hipSuccess) {
+                if (hipEventElapsedTime(&t, g_timer.ev[i][e], g_timer.ev[ST_PREPROCESS][0]) != hipSuccess) return -1;
+                t = -t;
+            }
+            ms[2 * i + e] = t;
+        }
+    }
+    return 0;
+}
+
 void gs2d_set_deterministic(int on) { g_deterministic.store(on != 0); }
 int gs2d_get_deterministic(void) { return g_deterministic.load(); }
 void gs2d_set_reference_binning(int on) { g_reference_binning.store(on != 0); }
@@ -235,6 +258,7 @@ struct FwdFrame {    // one frame: inputs, then the state the phases hand on
     size_t bin_bytes = 0;
     GeomLayout GL; CamParams cam;
     volatile uint32_t* pinned = nullptr;
+    bool fused_sort = false;     // the blend kernel sorts this frame's tile lists itself (phase -1)
     bool store_pending = false;  // the scan kernel WILL store into `pinned`: every return path first waits for that store
     int R = 0;
     gs2d::BlendFwdFrame bf;
@@ -412,8 +436,12 @@ int fwd_phase_b(const FwdShared& c, FwdFrame& f, int slot)
         g_timer.end(ST_RANGES, s);
         GS2D_STAGE("ranges");
     }
+    // The per-tile depth sort: as phase -1 of the blend kernel when the lists fit the LDS its workgroups hold anyway (packed
+    // pairs from the single-pass binning, capacity class 1536), else as the kernel of its own
+    f.fused_sort = one_pass && R > 0 && gs2d::tile_sort_capacity(R, IL.tiles) == GS2D_FUSED_SORT_CAP;
     if (R > 0) {
-        gs2d::launch_tile_depth_sort(R, IL.tiles, ranges, keys, point_list, keys_alt, vals_alt, one_pass ? 1 : 0, debug ? 1 : 0, s);
+        if (!f.fused_sort)
+            gs2d::launch_tile_depth_sort(R, IL.tiles, ranges, keys, point_list, keys_alt, vals_alt, one_pass ? 1 : 0, debug ? 1 : 0, s);
         g_timer.end(ST_SORT, s);
         GS2D_STAGE("tile depth sort");
     }
@@ -421,6 +449,7 @@ int fwd_phase_b(const FwdShared& c, FwdFrame& f, int slot)
     f.bf.out_color = f.out_color; f.bf.out_others = f.out_others; f.bf.pix_state = (float*)(img + IL.pix);
     f.bf.hits = (uint8_t*)(bin + BL.hits); f.bf.hits4 = (uint8_t*)(bin + BL.hits4);
     f.bf.zero = (float4*)(geom + GL.grad_rec);
+    f.bf.keys = keys; f.bf.keys_alt = keys_alt; f.bf.vals_alt = vals_alt;
     return 0;
 }
 
@@ -524,11 +553,18 @@ int fwd_batch_fused(const FwdShared& c, FwdFrame* f, int K)
         o.out_color = f[k].out_color; o.out_others = f[k].out_others; o.pix_state = (float*)(f[k].img + IL.pix);
         o.hits = (uint8_t*)(bn + BL.hits); o.hits4 = (uint8_t*)(bn + BL.hits4);
         o.zero = (float4*)(f[k].geom + GL.grad_rec);
+        o.keys = b.keys; o.keys_alt = b.keys_alt; o.vals_alt = b.vals_alt;
     }
     if (debug) GS2D_CHECK(hipStreamSynchronize(s), "scan (batch)");
     for (int k = K; k < GS2D_MAX_BATCH; k++) bin.f[k] = bin.f[0];
+    long long max_R = 0;
+    bool any_empty = false;
+    for (int k = 0; k < K; k++) { max_R = f[k].R > max_R ? f[k].R : max_R; any_empty = any_empty || f[k].R == 0; }
+    // (a frame without instances has no ranges to sort by: keep the stand-alone sort kernel for such a batch)
+    const bool fused_sort = !any_empty && gs2d::tile_sort_capacity(max_R, IL.tiles) == GS2D_FUSED_SORT_CAP;
+    for (int k = 0; k < K; k++) f[k].fused_sort = fused_sort;
     g_timer.begin(ST_SORT, s);
-    gs2d::launch_bin_sort_batch(P, K, IL.tiles, cam0.gx, tile_bits, bin, debug ? 1 : 0, s);
+    gs2d::launch_bin_sort_batch(P, K, IL.tiles, cam0.gx, tile_bits, bin, debug ? 1 : 0, /*depth_sort=*/!fused_sort, s);
     g_timer.end(ST_SORT, s);
     GS2D_STAGE("duplicate + sort (batch)");
     return 0;
@@ -541,7 +577,10 @@ int fwd_phase_c(const FwdShared& c, FwdFrame* frames, int K)
     gs2d::BlendFwdFrame bf[GS2D_MAX_BATCH];
     for (int k = 0; k < K; k++) bf[k] = frames[k].bf;
     g_timer.begin(ST_BLEND_FWD, s);
-    gs2d::launch_blend_fwd(c.width, c.height, K, bf, c.background, c.use_sa, (size_t)c.P * (GS2D_GRAD_FLOATS / 4), s);
+    bool fused = true;  // (all frames or none: the batch paths decide for the batch as a whole)
+    for (int k = 0; k < K; k++) fused = fused && frames[k].fused_sort;
+    gs2d::launch_blend_fwd(c.width, c.height, K, bf, c.background, c.use_sa, (size_t)c.P * (GS2D_GRAD_FLOATS / 4),
+                           fused ? GS2D_FUSED_SORT_CAP : 0, debug ? 1 : 0, s);
     const bool det = g_deterministic.load() != 0;
     for (int k = 0; k < K; k++) {
         FwdRecord fr;
@@ -769,7 +808,7 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
     return 0;
 }
 
-int gs2d_backward_batch(int K, const gs2d_frame_grad* fr, int P, int D, int M, const float* background, int width, int height,
+int gs2d_backward_batch(int K, const gs2d_frame_grad* fr, int accumulate, int P, int D, int M, const float* background, int width, int height,
                         const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
                         float scale_modifier, const float* rotations, const float* transMat_precomp, int use_sa, int debug,
                         void* stream)
@@ -838,6 +877,10 @@ int gs2d_backward_batch(int K, const gs2d_frame_grad* fr, int P, int D, int M, c
         gs2d::launch_preprocess_bwd_batch(P, K, D, M, means3D, shs, scales, rotations, /*need_record=*/scale_modifier != 1.0f, tab, s);
         g_timer.end(ST_PREPROCESS_BWD, s);
         GS2D_STAGE("preprocess_bwd (batch)");
+        if (accumulate && K > 1) {
+            gs2d::launch_sum_frames(P, K, shs != nullptr ? M : 0, tab, s);
+            GS2D_STAGE("sum over frames");
+        }
     }
     (void)colors_precomp; (void)transMat_precomp;
     return 0;

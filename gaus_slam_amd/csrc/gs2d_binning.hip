@@ -8,40 +8,10 @@
 // 8-bit digits, per-workgroup digit histograms -> device scan -> stable scatter using ballot-based
 // match-any ranking (64-wide), no CUB/rocPRIM.
 #include "gs2d_common.h"
+#include "gs2d_scan.h"
+#include "gs2d_tile_sort.h"
 
 namespace {
-
-// ---------------------------------------------------------------- device-wide inclusive scan (u32)
-// 3 kernels: per-block reduce, single-block scan of block sums, per-block scan + offset.
-constexpr int SCAN_T = 256;
-constexpr int SCAN_PER_T = GS2D_SCAN_ITEMS / SCAN_T;  // 4
-
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t n = __shfl_up(v, d, 64);
-        if (lane >= d) v += n;
-    }
-    return v;
-}
-
-// block-wide inclusive scan of one value per thread (256 threads); returns inclusive value, total in *total.
-__device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* total)
-{
-    __shared__ uint32_t wsum[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t inc = wave_incl_scan(v, lane);
-    __syncthreads();  // protect wsum reuse across calls
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    uint32_t base = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++)
-        if (w < wave) base += wsum[w];
-    if (total) *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    return inc + base;
-}
 
 __global__ void __launch_bounds__(SCAN_T) scan_reduce_kernel(const uint32_t* __restrict__ in, int n, uint32_t* __restrict__ block_sums)
 {
@@ -55,31 +25,6 @@ __global__ void __launch_bounds__(SCAN_T) scan_reduce_kernel(const uint32_t* __r
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// exclusive scan of block sums in place (single workgroup); writes the grand total.  Thread i owns the K = ceil(n/256)
-// consecutive sums [i K, (i+1) K): one round of loads, one workgroup scan of the 256 partial sums, one round of stores
-// (the chunk-by-chunk loop this replaces paid a load -> scan -> store -> barrier chain per 256 sums: 6.5 us for the 1954
-// sums of 500k Gaussians, on the path to the host's num_rendered).
-__device__ __forceinline__ void scan_blocksums_body(uint32_t* __restrict__ block_sums, int nblocks, uint32_t* __restrict__ total_out,
-                                                    uint32_t* __restrict__ total_host)
-{
-    const int K = (nblocks + SCAN_T - 1) / SCAN_T;
-    const int i0 = min(nblocks, (int)threadIdx.x * K), i1 = min(nblocks, i0 + K);
-    constexpr int KR = 8;  // sums kept in registers between the two rounds (more: re-read, they are cache hits)
-    uint32_t v[KR];
-    uint32_t mysum = 0;
-#pragma unroll
-    for (int j = 0; j < KR; j++) { v[j] = i0 + j < i1 ? block_sums[i0 + j] : 0u; mysum += v[j]; }
-    for (int i = i0 + KR; i < i1; i++) mysum += block_sums[i];
-    uint32_t total;
-    uint32_t running = block_incl_scan(mysum, &total) - mysum;
-    // pinned host word polled by the caller: published before the prefix is written back
-    if (threadIdx.x == 0 && total_host) __hip_atomic_store(total_host, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (threadIdx.x == 0 && total_out) *total_out = total;
-#pragma unroll
-    for (int j = 0; j < KR; j++)
-        if (i0 + j < i1) { block_sums[i0 + j] = running; running += v[j]; }
-    for (int i = i0 + KR; i < i1; i++) { const uint32_t x = block_sums[i]; block_sums[i] = running; running += x; }
-}
 __global__ void __launch_bounds__(SCAN_T) scan_blocksums_kernel(uint32_t* __restrict__ block_sums, int nblocks, uint32_t* __restrict__ total_out,
                                                                 uint32_t* __restrict__ total_host)
 {
@@ -409,122 +354,20 @@ __global__ void __launch_bounds__(BIN_T) bin_scatter_batch_kernel(int ntiles, in
                      f.hist + (size_t)ntiles * f.nblocks, f.nblocks, f.ranges);
 }
 
-// ---------------------------------------------------------------- per-tile depth sort (LDS)
-// After the global passes have binned the pairs by tile id (stable, so each tile's segment is still in Gaussian
-// order), one workgroup per tile sorts its segment by the 32 depth bits with a stable 4-pass LSD radix sort that
-// lives entirely in LDS ("LDS-staged per-tile splat lists").  The final order is identical to a global stable
-// sort on (tile | depth): LSD radix = sort by the low key first, then stably by the high key; here the high-key
-// pass simply ran first because the two keys are independent and the segment boundaries are known.
-// Segments longer than the LDS capacity take the same code path on global ping-pong buffers (flat pointers).
-__device__ void sort_segment_by_depth(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, int n,
-                                      uint32_t (*wcnt)[256])
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunk = ((n + 255) / 256) * 64;  // contiguous elements per wave, multiple of 64
-    const int beg = wave * chunk, end = min(n, beg + chunk);
-    const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    for (int pass = 0; pass < 4; pass++) {
-        const int shift = 8 * pass;
-        for (int i = threadIdx.x; i < 4 * 256; i += 256) (&wcnt[0][0])[i] = 0;
-        __syncthreads();
-        for (int i = beg + lane; i < end; i += 64) atomicAdd(&wcnt[wave][(ka[i] >> shift) & 255u], 1u);
-        __syncthreads();
-        {
-            const int d = threadIdx.x;
-            const uint32_t c0 = wcnt[0][d], c1 = wcnt[1][d], c2 = wcnt[2][d], c3 = wcnt[3][d];
-            const uint32_t tot = c0 + c1 + c2 + c3;
-            const uint32_t excl = block_incl_scan(tot, nullptr) - tot;
-            wcnt[0][d] = excl; wcnt[1][d] = excl + c0; wcnt[2][d] = excl + c0 + c1; wcnt[3][d] = excl + c0 + c1 + c2;
-        }
-        __syncthreads();
-        for (int i0 = beg; i0 < end; i0 += 64) {
-            const int i = i0 + lane;
-            const bool valid = i < end;
-            const uint32_t k = valid ? ka[i] : 0u;
-            const uint32_t v = valid ? va[i] : 0u;
-            const uint32_t d = (k >> shift) & 255u;
-            uint64_t peers = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 8; b++) {
-                const uint64_t vote = __ballot((d >> b) & 1u);
-                peers &= ((d >> b) & 1u) ? vote : ~vote;
-            }
-            const uint32_t before = wcnt[wave][d];
-            __builtin_amdgcn_wave_barrier();
-            if (valid && (peers & lt_mask) == 0) wcnt[wave][d] = before + (uint32_t)__popcll(peers);
-            __builtin_amdgcn_wave_barrier();
-            if (valid) {
-                const uint32_t dst = before + (uint32_t)__popcll(peers & lt_mask);
-                kb[dst] = k;
-                vb[dst] = v;
-            }
-        }
-        __syncthreads();
-        uint32_t* t = ka; ka = kb; kb = t;
-        t = va; va = vb; vb = t;
-    }
-}
-
-// packed != 0: the segment holds (depth bits, id) pairs in the 8-byte key slots (output of bin_scatter_kernel);
-// packed == 0: 64-bit keys + separate ids (output of the generic radix passes).  The sorted ids always land in `vals`
-// (the point list); the full 64-bit keys are materialised only when write_keys != 0 (debug / parity tests).
-__device__ __forceinline__ void
-tile_depth_sort_body(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                     uint64_t* __restrict__ keys_alt, uint32_t* __restrict__ vals_alt, int cap, int packed, int write_keys)
-{
-    extern __shared__ uint32_t dyn[];  // [4][cap]: ka, va, kb, vb
-    __shared__ uint32_t wcnt[4][256];
-    const int tile = blockIdx.x;
-    const uint2 r = ranges[tile];
-    const int n = (int)(r.y - r.x);
-    if (n <= 0) return;
-    uint64_t* kseg = keys + r.x;
-    uint32_t* vseg = vals + r.x;
-    const uint2* pseg = reinterpret_cast<const uint2*>(kseg);
-    const uint64_t hi = (uint64_t)(uint32_t)tile << 32;
-    if (n <= cap) {
-        uint32_t *ka = dyn, *va = dyn + cap, *kb = dyn + 2 * cap, *vb = dyn + 3 * cap;
-        for (int i = threadIdx.x; i < n; i += 256) {
-            if (packed) { const uint2 p = pseg[i]; ka[i] = p.x; va[i] = p.y; }
-            else { ka[i] = (uint32_t)kseg[i]; va[i] = vseg[i]; }
-        }
-        __syncthreads();
-        if (n > 1) sort_segment_by_depth(ka, va, kb, vb, n, wcnt);  // 4 passes: result back in ka / va
-        for (int i = threadIdx.x; i < n; i += 256) {
-            vseg[i] = va[i];
-            if (write_keys) kseg[i] = hi | ka[i];
-        }
-    } else {
-        // oversized list: same algorithm on global ping-pong arrays carved from the segment's own scratch slots:
-        // ka, va = the two halves of the segment's keys_alt slots, kb = its vals_alt slots, vb = its point-list slots
-        uint32_t* ka = reinterpret_cast<uint32_t*>(keys_alt + r.x);
-        uint32_t* va = ka + n;
-        uint32_t* kb = vals_alt + r.x;
-        uint32_t* vb = vseg;
-        if (packed) {
-            for (int i = threadIdx.x; i < n; i += 256) { const uint2 p = pseg[i]; ka[i] = p.x; va[i] = p.y; }
-        } else {
-            // vseg doubles as vb, so the ids are copied out first
-            for (int i = threadIdx.x; i < n; i += 256) { ka[i] = (uint32_t)kseg[i]; va[i] = vseg[i]; }
-        }
-        __syncthreads();
-        sort_segment_by_depth(ka, va, kb, vb, n, wcnt);  // even number of passes: result in ka / va
-        for (int i = threadIdx.x; i < n; i += 256) {
-            vseg[i] = va[i];
-            if (write_keys) kseg[i] = hi | ka[i];
-        }
-    }
-}
 __global__ void __launch_bounds__(256)
 tile_depth_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
                        uint64_t* __restrict__ keys_alt, uint32_t* __restrict__ vals_alt, int cap, int packed, int write_keys)
 {
-    tile_depth_sort_body(ranges, keys, vals, keys_alt, vals_alt, cap, packed, write_keys);
+    extern __shared__ uint32_t dyn[];  // [4][cap]: ka, va, kb, vb
+    __shared__ uint32_t wcnt[4][256];
+    tile_depth_sort_body(blockIdx.x, dyn, wcnt, ranges, keys, vals, keys_alt, vals_alt, cap, packed, write_keys);
 }
 __global__ void __launch_bounds__(256) tile_depth_sort_batch_kernel(int cap, int write_keys, const gs2d::BinFrames tab)
 {
     const gs2d::BinFrame& f = tab.f[blockIdx.y];
-    if (f.R > 0) tile_depth_sort_body(f.ranges, f.keys, f.point_list, f.keys_alt, f.vals_alt, cap, 1, write_keys);
+    extern __shared__ uint32_t dyn[];
+    __shared__ uint32_t wcnt[4][256];
+    if (f.R > 0) tile_depth_sort_body(blockIdx.x, dyn, wcnt, f.ranges, f.keys, f.point_list, f.keys_alt, f.vals_alt, cap, 1, write_keys);
 }
 
 // rasterizer_impl.cu:116-138
@@ -605,6 +448,13 @@ bool launch_bin_by_tile(int R, int tiles, int nbits, const uint64_t* keys_in, co
     return true;
 }
 
+int tile_sort_capacity(long long R, int tiles)
+{
+    if (tiles <= 0) return 1536;
+    const int want = (int)((R * 13) / ((long long)tiles * 10));
+    return want <= 1536 ? 1536 : (want <= 2048 ? 2048 : (want <= 3072 ? 3072 : 4096));
+}
+
 void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt,
                             uint32_t* vals_alt, int packed, int write_keys, hipStream_t s)
 {
@@ -612,8 +462,7 @@ void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* key
     // LDS capacity per tile: the smallest of 1536 / 2048 / 3072 / 4096 elements (16 B each, <= 64 KB dynamic LDS) that
     // is at least 1.3x the mean list length.  Smaller capacity = more workgroups per CU (1536 -> 5 per CU, i.e. all
     // 1200 tiles of a 640x480 frame resident at once); the few tiles above the capacity take the global-memory variant.
-    const int want = (int)(((long long)R * 13) / ((long long)tiles * 10));
-    const int cap = want <= 1536 ? 1536 : (want <= 2048 ? 2048 : (want <= 3072 ? 3072 : 4096));
+    const int cap = tile_sort_capacity(R, tiles);
     hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(tiles), dim3(256), (size_t)cap * 16, s, ranges, keys, vals, keys_alt,
                        vals_alt, cap, packed, write_keys);
 }
@@ -624,7 +473,7 @@ void launch_offsets_blocksums_batch(int P, int K, const BinFrames& tab, hipStrea
 }
 
 // duplicate + the single-pass tile binning + the per-tile depth sort for K frames, five launches in all (tiles <= GS2D_BIN_MAX_TILES)
-void launch_bin_sort_batch(int P, int K, int tiles, int gx, int nbits, BinFrames& tab, int write_keys, hipStream_t s)
+void launch_bin_sort_batch(int P, int K, int tiles, int gx, int nbits, BinFrames& tab, int write_keys, bool depth_sort, hipStream_t s)
 {
     int max_blocks = 0;
     long long max_R = 0;
@@ -639,8 +488,8 @@ void launch_bin_sort_batch(int P, int K, int tiles, int gx, int nbits, BinFrames
     hipLaunchKernelGGL(bin_hist_batch_kernel, dim3(max_blocks, K), dim3(BIN_T), (size_t)tiles * 4, s, tiles, tab);
     hipLaunchKernelGGL(bin_row_scan_batch_kernel, dim3((tiles + 3) / 4, K), dim3(256), 0, s, tiles, tab);
     hipLaunchKernelGGL(bin_scatter_batch_kernel, dim3(max_blocks, K), dim3(BIN_T), (size_t)tiles * 16, s, tiles, nbits, tab);
-    const int want = (int)((max_R * 13) / ((long long)tiles * 10));  // (launch_tile_depth_sort's rule, on the longest frame)
-    const int cap = want <= 1536 ? 1536 : (want <= 2048 ? 2048 : (want <= 3072 ? 3072 : 4096));
+    if (!depth_sort) return;  // the forward blend kernel sorts each tile's list itself
+    const int cap = tile_sort_capacity(max_R, tiles);  // (launch_tile_depth_sort's rule, on the longest frame)
     hipLaunchKernelGGL(tile_depth_sort_batch_kernel, dim3(tiles, K), dim3(256), (size_t)cap * 16, s, cap, write_keys, tab);
 }
 

@@ -21,6 +21,7 @@
 // per-pixel recurrences reproduce the CPU oracle up to the ulp-level difference of v_exp_f32 / v_rcp_f32.
 #include "gs2d_common.h"
 #include "gs2d_cull.h"
+#include "gs2d_tile_sort.h"
 #include "gs2d_blend_dev.h"  // dev-only probes (wave profile, ingredient pricing): all pass-through in the product build
 
 #include <type_traits>
@@ -191,9 +192,12 @@ __device__ __forceinline__ void clear_share(float4* __restrict__ zero, size_t ze
 template <bool USE_SA, bool BATCH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS2D_FWD_WAVES_PER_EU, GS2D_FWD_WAVES_PER_EU)))
 blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const float* __restrict__ bg, size_t plane, size_t zero_n,
-                 const std::conditional_t<BATCH, gs2d::BlendFwdBatch, gs2d::BlendFwdFrame> args)
+                 int sort_cap, int write_keys, const std::conditional_t<BATCH, gs2d::BlendFwdBatch, gs2d::BlendFwdFrame> args)
 {
-    __shared__ FwdBatch batches[4];
+    // ONE dynamic LDS region, used twice: by the depth sort of phase -1 (4 x sort_cap words + 4 x 256 digit counters) and then by
+    // the four waves' staging batches (launch_blend_fwd sizes it for the larger of the two)
+    extern __shared__ uint32_t dyn_lds[];
+    FwdBatch* batches = reinterpret_cast<FwdBatch*>(dyn_lds);
     int local_block = blockIdx.x;
     const gs2d::BlendFwdFrame* fa;
     if constexpr (BATCH) {
@@ -214,6 +218,18 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     float4* __restrict__ zero = fa->zero;
     const int tile = xcd_tile(local_block, ntiles);
     if (tile < 0) { clear_share(zero, zero_n, local_block, blocks_per_frame); return; }
+    // phase -1 (sort_cap > 0): this tile's list, binned by the counting sort in Gaussian order, is sorted by depth here --
+    // the per-tile LDS radix sort that used to be a kernel of its own (22 us + a dependent dispatch at 640x480 / 500k), with
+    // the same workgroup-per-tile shape; now tiles that sort overlap with tiles that already blend.  The sorted ids go to
+    // point_list in global memory (the backward and the cull phase read them); workgroup scope is enough for the waves of
+    // this workgroup to see them (see phase 0).
+    if (sort_cap > 0) {
+        tile_depth_sort_body(tile, dyn_lds, reinterpret_cast<uint32_t (*)[256]>(dyn_lds + 4 * sort_cap), fa->ranges, fa->keys,
+                             fa->point_list, fa->keys_alt, fa->vals_alt, sort_cap, /*packed=*/1, write_keys);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     const int tx = tile % gx, ty = tile / gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     FwdBatch& wb = batches[wave];
@@ -301,7 +317,11 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
         dq = (dq | (dq >> 6)) & 0x000F000F000F000Full;
         dq = (dq | (dq >> 12)) & 0x000000FF000000FFull;
         const uint32_t done16 = (uint32_t)(dq | (dq >> 24)) & 0xFFFFu;         // ... bit g: group g is finished
+#ifdef GS2D_NO_DONE16  // dev A/B switch (scripts/dev/variants.sh)
+        const uint32_t nib = lane < fill ? (uint32_t)wb.tm[lane] : 0u; (void)done16;
+#else
         const uint32_t nib = lane < fill ? (uint32_t)wb.tm[lane] & ~done16 : 0u;
+#endif
         int trips = 0;  // the longest queue (0: everything staged belongs to finished groups -- the trip loop then runs one idle step)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -779,10 +799,12 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
         // four depth-ordered queues, one per 4x4 sub-block (= DPP row): byte lists of slot numbers, deepest (= highest
         // slot) first, so walking a list front to back visits the row's splats back to front
         uint32_t nib = lane >= 64 - fill ? wb.pn[lane] : 0u;
+#ifndef GS2D_NO_ROW_LAST  // dev A/B switch (scripts/dev/variants.sh)
         {   // row r keeps the splat only if it lies in front of the row's deepest contributor (pos < row_last_r)
             const uint32_t pos = nib >> 4;
             nib &= (pos < row_last0 ? 1u : 0u) | (pos < row_last1 ? 2u : 0u) | (pos < row_last2 ? 4u : 0u) | (pos < row_last3 ? 8u : 0u);
         }
+#endif
         const uint64_t m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u), m2 = __ballot(nib & 4u), m3 = __ballot(nib & 8u);
         const int len0 = __popcll(m0), len1 = __popcll(m1), len2 = __popcll(m2), len3 = __popcll(m3);
         // every entry past a queue's end reads 252 + row = "exhausted" (any value >= 64; distinct per row for the
@@ -1004,25 +1026,32 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
 
 namespace gs2d {
 
-void launch_blend_fwd(int W, int H, int K, const BlendFwdFrame* frames, const float* bg, int use_sa, size_t zero_n, hipStream_t s)
+void launch_blend_fwd(int W, int H, int K, const BlendFwdFrame* frames, const float* bg, int use_sa, size_t zero_n, int sort_cap,
+                      int write_keys, hipStream_t s)
 {
     const int gx = (W + GS2D_TILE - 1) / GS2D_TILE, gy = (H + GS2D_TILE - 1) / GS2D_TILE;
     const size_t plane = (size_t)gx * gy * GS2D_TILE_PIX;
     const int bpf = GS2D_XCDS * ((gx * gy + GS2D_XCDS - 1) / GS2D_XCDS);  // a multiple of 8: blockIdx % 8 picks the same XCD in every frame
+    size_t lds = 4 * sizeof(FwdBatch);
+    if (sort_cap > 0 && (size_t)sort_cap * 16 + 4096 > lds) lds = (size_t)sort_cap * 16 + 4096;  // (28 KB at 1536: still 5 workgroups per CU)
     if (K == 1) {
         if (use_sa)
-            hipLaunchKernelGGL((blend_fwd_kernel<true, false>), dim3(bpf), dim3(256), 0, s, W, H, gx, gx * gy, bpf, bg, plane, zero_n, frames[0]);
+            hipLaunchKernelGGL((blend_fwd_kernel<true, false>), dim3(bpf), dim3(256), lds, s, W, H, gx, gx * gy, bpf, bg, plane, zero_n,
+                               sort_cap, write_keys, frames[0]);
         else
-            hipLaunchKernelGGL((blend_fwd_kernel<false, false>), dim3(bpf), dim3(256), 0, s, W, H, gx, gx * gy, bpf, bg, plane, zero_n, frames[0]);
+            hipLaunchKernelGGL((blend_fwd_kernel<false, false>), dim3(bpf), dim3(256), lds, s, W, H, gx, gx * gy, bpf, bg, plane, zero_n,
+                               sort_cap, write_keys, frames[0]);
         return;
     }
     BlendFwdBatch b;
     for (int k = 0; k < K; k++) b.f[k] = frames[k];
     for (int k = K; k < GS2D_MAX_BATCH; k++) b.f[k] = frames[0];
     if (use_sa)
-        hipLaunchKernelGGL((blend_fwd_kernel<true, true>), dim3(bpf * K), dim3(256), 0, s, W, H, gx, gx * gy, bpf, bg, plane, zero_n, b);
+        hipLaunchKernelGGL((blend_fwd_kernel<true, true>), dim3(bpf * K), dim3(256), lds, s, W, H, gx, gx * gy, bpf, bg, plane, zero_n,
+                           sort_cap, write_keys, b);
     else
-        hipLaunchKernelGGL((blend_fwd_kernel<false, true>), dim3(bpf * K), dim3(256), 0, s, W, H, gx, gx * gy, bpf, bg, plane, zero_n, b);
+        hipLaunchKernelGGL((blend_fwd_kernel<false, true>), dim3(bpf * K), dim3(256), lds, s, W, H, gx, gx * gy, bpf, bg, plane, zero_n,
+                           sort_cap, write_keys, b);
 }
 
 void launch_blend_bwd(int W, int H, int K, const BlendBwdFrame* frames, const float* bg, int use_sa, float* clear12, int clear_n,

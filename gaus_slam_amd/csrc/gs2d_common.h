@@ -227,6 +227,8 @@ void launch_preprocess_fwd_batch(int P, int K, int D, int M, const float* means3
                                  const float* colors_precomp, const CamParams& cam0, const PreFwdFrames& tab, hipStream_t s);
 void launch_preprocess_bwd_batch(int P, int K, int D, int M, const float* means3D, const float* shs, const float* scales,
                                  const float* rotations, int need_record, const PreBwdFrames& tab, hipStream_t s);
+// frame 0's dL_* outputs += those of frames 1 .. K-1, in frame order (fields that are NULL in frame 0 are skipped)
+void launch_sum_frames(int P, int K, int M, const PreBwdFrames& tab, hipStream_t s);
 
 // Per-frame pointers of the binning chain (duplicate, tile binning, depth sort) in the batched forward.
 struct BinFrame {
@@ -243,16 +245,21 @@ struct BinFrame {
 };
 struct BinFrames { BinFrame f[8]; };
 void launch_offsets_blocksums_batch(int P, int K, const BinFrames& tab, hipStream_t s);
-void launch_bin_sort_batch(int P, int K, int tiles, int gx, int nbits, BinFrames& tab, int write_keys, hipStream_t s);
+// depth_sort = false: stop after the scatter (the forward blend kernel then sorts every tile's list as its first phase)
+void launch_bin_sort_batch(int P, int K, int tiles, int gx, int nbits, BinFrames& tab, int write_keys, bool depth_sort, hipStream_t s);
+// LDS capacity (elements) launch_tile_depth_sort picks for R instances on `tiles` tiles: 1536 / 2048 / 3072 / 4096
+int tile_sort_capacity(long long R, int tiles);
+#define GS2D_FUSED_SORT_CAP 1536  // the capacity at which the depth sort fits the LDS a forward blend workgroup holds anyway
 
 // Per-frame pointers of the blend kernels.  A launch handles K frames of the same size over the same Gaussians (K = 1: the
 // plain call; K > 1: gs2d_forward_batch / gs2d_backward_batch, one grid over K x tiles).
 #define GS2D_MAX_BATCH 8
 struct BlendFwdFrame {
-    const uint2* ranges; const uint32_t* point_list; const float4* rec;
+    const uint2* ranges; uint32_t* point_list; const float4* rec;
     float* out_color; float* out_others; float* pix_state;
     uint8_t* hits; uint8_t* hits4;  // written by phase 0 (cull bits, gs2d_cull.h)
     float4* zero;                   // the backward's gradient accumulator, cleared with the kernel's idle store slots
+    uint64_t* keys; uint64_t* keys_alt; uint32_t* vals_alt;  // sort_cap > 0: the binned (depth, id) pairs of the tile lists + scratch
 };
 struct BlendFwdBatch { BlendFwdFrame f[GS2D_MAX_BATCH]; };
 struct BlendBwdFrame {
@@ -265,7 +272,10 @@ struct BlendBwdBatch { BlendBwdFrame f[GS2D_MAX_BATCH]; };
 // Writes hits (u16[4 * i + q] = the 2x2 pixel groups of quadrant q that instance i of the sorted list can touch, see
 // gs2d_cull.h) for every instance, then blends.  Also clears zero_n float4 at `zero` (the backward's gradient accumulator)
 // with its idle store slots.
-void launch_blend_fwd(int W, int H, int K, const BlendFwdFrame* frames, const float* bg, int use_sa, size_t zero_n, hipStream_t s);
+// sort_cap > 0 (= GS2D_FUSED_SORT_CAP): every workgroup first sorts its tile's list by depth (the per-tile depth sort as phase
+// -1, lists longer than sort_cap through global scratch), write_keys as in launch_tile_depth_sort
+void launch_blend_fwd(int W, int H, int K, const BlendFwdFrame* frames, const float* bg, int use_sa, size_t zero_n, int sort_cap,
+                      int write_keys, hipStream_t s);
 // clear12 (optional): clear_n floats zeroed by the kernel (the pose-gradient sums the next stage accumulates into).
 void launch_blend_bwd(int W, int H, int K, const BlendBwdFrame* frames, const float* bg, int use_sa, float* clear12, int clear_n,
                       hipStream_t s);

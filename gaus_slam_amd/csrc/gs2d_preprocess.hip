@@ -643,6 +643,40 @@ preprocess_bwd_batch_kernel(int P, int D, int M, const float* __restrict__ means
                            f.dL_drot, nullptr, nullptr, pg);
 }
 
+// gs2d_backward_batch(accumulate = 1): frame 0's outputs += frame 1's + ... + frame K-1's, added in frame order (the sums K
+// separate backwards followed by tensor additions produce, bit for bit) -- one launch instead of 6 (K - 1) elementwise kernels
+__global__ void __launch_bounds__(256) sum_frames_kernel(int P, int K, int M, const gs2d::PreBwdFrames tab)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= P) return;
+#define GS2D_SUM_FIELD(F, N)                                                                                   \
+    if (tab.f[0].F != nullptr) {                                                                                \
+        float v[N];                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < N; i++) v[i] = tab.f[0].F[(size_t)g * N + i];                     \
+        for (int k = 1; k < K; k++) {                                                                           \
+            const float* __restrict__ sp = tab.f[k].F;                                                          \
+            _Pragma("unroll") for (int i = 0; i < N; i++) v[i] += sp[(size_t)g * N + i];                        \
+        }                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < N; i++) tab.f[0].F[(size_t)g * N + i] = v[i];                     \
+    }
+    GS2D_SUM_FIELD(dL_dmean2D, 3)
+    GS2D_SUM_FIELD(dL_dmean3D, 3)
+    GS2D_SUM_FIELD(dL_dcolor, 3)
+    GS2D_SUM_FIELD(dL_dopacity, 1)
+    GS2D_SUM_FIELD(dL_dscale, 2)
+    GS2D_SUM_FIELD(dL_drot, 4)
+    GS2D_SUM_FIELD(dL_dnormal, 3)
+    GS2D_SUM_FIELD(dL_dtransMat, 9)
+#undef GS2D_SUM_FIELD
+    if (tab.f[0].dL_dsh != nullptr && M > 0) {
+        for (int i = 0; i < 3 * M; i++) {
+            float v = tab.f[0].dL_dsh[(size_t)g * 3 * M + i];
+            for (int k = 1; k < K; k++) v += tab.f[k].dL_dsh[(size_t)g * 3 * M + i];
+            tab.f[0].dL_dsh[(size_t)g * 3 * M + i] = v;
+        }
+    }
+}
+
 // Deterministic pose gradient: dL_dpose[c] += sum over the workgroups' partials, always in the same order (lane l adds
 // partials l, l + 64, ... one after the other, then a fixed butterfly over the 64 lanes).
 __global__ void __launch_bounds__(64) pose_reduce_kernel(int n, const float* __restrict__ partials, float* __restrict__ dL_dpose)
@@ -699,6 +733,12 @@ void launch_preprocess_bwd_batch(int P, int K, int D, int M, const float* means3
     const int use_rec = (scales == nullptr || need_record) ? 1 : 0;
     hipLaunchKernelGGL(preprocess_bwd_batch_kernel, dim3((P + 255) / 256, K), dim3(256), 0, s, P, D, M, means3D, shs, scales, rotations,
                        use_rec, tab);
+}
+
+void launch_sum_frames(int P, int K, int M, const PreBwdFrames& tab, hipStream_t s)
+{
+    if (P <= 0 || K <= 1) return;
+    hipLaunchKernelGGL(sum_frames_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, K, M, tab);
 }
 
 void launch_preprocess_bwd(int first, int P, int D, int M, const float* means3D, const float4* rec, const int* radii,

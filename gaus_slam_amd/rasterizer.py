@@ -303,9 +303,10 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
 def rasterize_gaussians_backward_batch(background, means3D, radii, colors, scales, rotations, scale_modifier, transMat_precomp,
                                        viewmatrices, projmatrices, tan_fovxs, tan_fovys, dL_dout_color, dL_dout_others, sh,
                                        degree, camposs, geomBuffers, Rs, binningBuffers, imageBuffers, use_sa, debug,
-                                       grad_sink=None, lean=False):
+                                       grad_sink=None, lean=False, accumulate=False):
     """gs2d_backward_batch: the backward of rasterize_gaussians_batch.  Returns a list of K tuples, frame k's being exactly
-    what rasterize_gaussians_backward returns for that frame (per-frame gradients; the caller sums them).
+    what rasterize_gaussians_backward returns for that frame (per-frame gradients).
+    accumulate: frame 0's tensors additionally receive the SUM over all frames (added in frame order, in one kernel).
     grad_sink: as in rasterize_gaussians_backward, for frame 0's parameter gradients."""
     L = _lib.lib()
     dev = means3D.device
@@ -351,7 +352,7 @@ def rasterize_gaussians_backward_batch(background, means3D, radii, colors, scale
             f.dL_dcolor, f.dL_dmean3D, f.dL_dtransMat = o["colors"].data_ptr(), o["means3D"].data_ptr(), _ptr(o["transMat"])
             f.dL_dsh, f.dL_dscale, f.dL_drot = _ptr(o["sh"]), o["scales"].data_ptr(), o["rotations"].data_ptr()
         with _on_device(dev):
-            rc = L.gs2d_backward_batch(K, fr, P, int(degree), M, _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(sc_),
+            rc = L.gs2d_backward_batch(K, fr, int(bool(accumulate)), P, int(degree), M, _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(sc_),
                                        float(scale_modifier), _ptr(rot_), _ptr(tm_), int(bool(use_sa)), int(bool(debug)),
                                        _stream_ptr(dev))
     if rc < 0:
@@ -543,12 +544,8 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         per = rasterize_gaussians_backward_batch(
             rs0.bg, means3D, radii, colors_precomp, scales, rotations, rs0.scale_modifier, cov3Ds_precomp, vms, pms,
             [rs.tanfovx for rs in ctx.settings_list], [rs.tanfovy for rs in ctx.settings_list], grad_out_color, grad_depth, sh,
-            rs0.sh_degree, cps, geoms, ctx.Rs, bins, imgs, rs0.use_sa, rs0.debug, grad_sink=sink, lean=True)
-        total = list(per[0])
-        for k in range(1, K):  # frame order: the same sums K separate backwards accumulate
-            for i, g in enumerate(per[k]):
-                if g is not None and total[i] is not None:
-                    total[i].add_(g)
+            rs0.sh_degree, cps, geoms, ctx.Rs, bins, imgs, rs0.use_sa, rs0.debug, grad_sink=sink, lean=True, accumulate=True)
+        total = per[0]  # frame order: the same sums K separate backwards accumulate (one kernel, gs2d_backward_batch(accumulate))
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = total
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,

@@ -213,8 +213,11 @@ typedef struct gs2d_frame_grad {     /* per-frame arguments of gs2d_backward (sa
     float* dL_dmean2D; float* dL_dnormal; float* dL_dopacity; float* dL_dcolor; float* dL_dmean3D;
     float* dL_dtransMat; float* dL_dsh; float* dL_dscale; float* dL_drot;
 } gs2d_frame_grad;
+/* accumulate != 0: after the per-frame gradients have been written, frame 0's dL_* arrays receive the sum over all K frames
+ * (added in frame order: the result K separate backwards followed by tensor additions give) -- what a BA rank needs; frames
+ * 1 .. K-1 still hold their own gradients. */
 int gs2d_backward_batch(
-    int K, const gs2d_frame_grad* frames, int P, int D, int M, const float* background, int width, int height,
+    int K, const gs2d_frame_grad* frames, int accumulate, int P, int D, int M, const float* background, int width, int height,
     const float* means3D, const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
     const float* rotations, const float* transMat_precomp, int use_sa, int debug, void* stream);
 
@@ -310,6 +313,8 @@ void gs2d_image_layout(int width, int height, size_t offsets[2]);
  * (cull: always -1, the sub-block cull runs as the first phase of blend_fwd). */
 void gs2d_stage_timing_enable(int on);
 int gs2d_stage_timing_read(float ms[9]);
+/* ms[2 i], ms[2 i + 1] = begin / end of stage i relative to the begin of the latest preprocess stage (-1: not recorded). */
+int gs2d_stage_timing_read_abs(float ms[18]);
 
 const char* gs2d_last_error(void);
 const char* gs2d_build_info(void);

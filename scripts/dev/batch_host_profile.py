@@ -49,3 +49,17 @@ for rep in range(3):
     torch.cuda.synchronize(); tend = time.perf_counter()
     d = np.diff(ts) * 1e3
     print(f"20-step window: {(tend - ts[0]) / 20 * 1e3:.3f} ms/step; host return times per step (ms): " + " ".join(f"{x:.2f}" for x in d) + f"; drain {1e3 * (tend - ts[-1]):.2f}")
+
+# stream timeline of one step from the library's stage events (begin/end relative to the step's first kernel)
+import ctypes as C
+from gaus_slam_amd import _lib
+L = _lib.lib()
+L.gs2d_stage_timing_enable(1)
+names = ["preprocess", "scan", "duplicate", "sort", "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "cull"]
+for rep in range(3):
+    for _ in range(6): ba.step(kfs)
+    buf = (C.c_float * 18)()
+    L.gs2d_stage_timing_read_abs(buf)
+    ev = sorted((buf[2 * i], buf[2 * i + 1], n) for i, n in enumerate(names) if buf[2 * i + 1] >= 0 or buf[2 * i] != -1.0)
+    print("timeline (us): " + "  ".join(f"{n} {b * 1e3:.0f}..{e * 1e3:.0f}" for b, e, n in ev if n not in ("ranges", "cull")))
+L.gs2d_stage_timing_enable(0)

@@ -88,6 +88,21 @@ def test_batch_equals_separate_calls(K, P, W, H, use_sa):
             if name not in ("transMat",):
                 assert np.abs(b).max() > 0, (k, name)
             assert util.grad_err(a, b) <= 1e-5, (k, name)
+    # accumulate: frame 0's tensors hold the sum over the frames, added in frame order (== the tensor sums of the per-frame
+    # gradients of the same call, bit for bit: same operands, same order)
+    g_acc = rasterizer.rasterize_gaussians_backward_batch(
+        x["bg"], x["means3D"], radii, x["colors"], x["scales"], x["rots"], 1.0, x["e"], vms, pms, [c.tanfovx for c in cams],
+        [c.tanfovy for c in cams], torch.stack(dcs), torch.stack(das), x["e"], 0, cps, geoms, Rs, bins, imgs, use_sa, False,
+        accumulate=True)
+    torch.cuda.synchronize()
+    for i, name in enumerate(GRAD_KEYS):
+        if name == "sh":
+            continue
+        tot = g_acc[1][i].clone()          # frames 1..K-1 keep their own gradients: rebuild the sum from this same call
+        for k in range(2, K):
+            tot = tot + g_acc[k][i]
+        ref = g_bat[0][i].double() + sum(g_bat[k][i].double() for k in range(1, K))
+        assert util.grad_err(g_acc[0][i].double().cpu().numpy(), ref.cpu().numpy()) <= 1e-5, name
     # a second batched backward on the same forward state (accumulators no longer known clean) gives the same result
     g_bat2 = rasterizer.rasterize_gaussians_backward_batch(
         x["bg"], x["means3D"], radii, x["colors"], x["scales"], x["rots"], 1.0, x["e"], vms, pms, [c.tanfovx for c in cams],
