@@ -267,6 +267,7 @@ struct FwdFrame {    // one frame: inputs, then the state the phases hand on
 int fwd_validate(const FwdShared& c)
 {
     if (c.P < 0 || c.width <= 0 || c.height <= 0) return fail_msg("bad sizes");
+    if (c.P >= (1 << 28)) return fail_msg("more than 2^28 - 1 Gaussians (the backward packs the Gaussian id into 28 bits)");
     if (c.P == 0) return 0;
     if (c.colors_precomp == nullptr && c.shs == nullptr) return fail_msg("provide shs or colors_precomp");
     if (c.transMat_precomp == nullptr && (c.scales == nullptr || c.rotations == nullptr))

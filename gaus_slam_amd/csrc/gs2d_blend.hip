@@ -60,6 +60,11 @@ __device__ __forceinline__ void fwd_eval(const float4 q0, const float4 q1, const
     ok = !(p2 == 0.0f) && !(depth < GS2D_NEAR_N) && !(rho < 0.0f) && !(alpha < 1.0f / 255.0f);
 }
 
+// Lane mask of a predicate.  The ballot builtin takes the predicate as a bool, so a test like `ballot64(x) != 0` compiles to a
+// scalar compare of the mask the v_cmp already produced; hip's __ballot(int) goes through an integer compare of a materialised
+// 0/1 (v_cndmask + v_cmp on the vector unit in every trip of both blend loops).
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // Wave-private LDS: operations of one wave execute in order; the fence only stops the compiler from reordering them.
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -113,8 +118,11 @@ __device__ __forceinline__ int pop_back(uint64_t& m)
 // trip count is the LONGEST queue instead of the whole list, the VALU executes only per-pixel math and the scalar unit
 // only the loop counter (round 1 popped 64-bit bit-queues with ~65 scalar instructions per trip).
 struct FwdBatch {
-    float4 q[GS2D_REC_F4][64];  // staged records, SoA by quarter
-    uint8_t ql[16][64];         // per-group queues: slot numbers in depth order, 255 = end
+    float4 qf[GS2D_REC_F4 * 64];  // staged records, SoA by quarter (q(k)[slot])
+    uint8_t ql[16][64];           // per-group queues: slot numbers in depth order, 64 = end.  The trip loop indexes records with
+                                  // the marker unmasked: an exhausted group reads the next quarter's slot 0 (the last quarter:
+                                  // the first queue bytes) -- inside this struct, never used (the group is not live)
+    __device__ __forceinline__ float4* q(int k) { return qf + k * 64; }
     uint32_t tail[4];           // the pipeline reads up to two entries past a full queue (values unused)
     uint16_t tm[64];            // group bits of the staged splats
 };
@@ -251,6 +259,9 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const uint8_t* qrow = wb.ql[row];
+    // the bytes behind the queues (the pipeline reads up to two entries past a full queue): wave-private, written once (the
+    // LDS was the depth sort's until the barrier above)
+    if (lane < 4) wb.tail[lane] = 0x40404040u;
 
     float T = 1.0f, C0_ = 0.f, C1_ = 0.f, C2_ = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
     float Dp = 0.f, M1 = 0.f, M2 = 0.f, D2 = 0.f, distortion = 0.f, median_depth = 0.f;
@@ -271,7 +282,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     uint32_t pf_tm = hits16[(size_t)min(next_chunk + lane, last_i) * 4 + wave];
     uint32_t pf_id = point_list[min(next_chunk + lane, last_i)];
     for (;;) {
-        if (__ballot(!done) == 0) break;
+        if (ballot64(!done) == 0) break;
         prio_by_remaining<GS2D_FWD_PRIO_SHIFT>(range.y - min(next_chunk, range.y), range.y - range.x);
         int fill = 0;
         GS2D_PROF_STAGE_BEGIN();
@@ -287,7 +298,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                 pf_tm = hits16[(size_t)min(next_chunk + lane, last_i) * 4 + wave];
                 pf_id = point_list[min(next_chunk + lane, last_i)];
             }
-            const uint64_t tb = __ballot(tm != 0u);
+            const uint64_t tb = ballot64(tm != 0u);
             const int c = __popcll(tb);
             if (c == 0) continue;
             const int slot = fill + rank_below(tb);
@@ -297,7 +308,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                 const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
                 float4 r4 = rp[4];
                 r4.w = __uint_as_float(cbase - range.x + lane);  // the list position rides in the free slot
-                wb.q[0][slot] = r0; wb.q[1][slot] = r1; wb.q[2][slot] = r2; wb.q[3][slot] = r3; wb.q[4][slot] = r4;
+                wb.q(0)[slot] = r0; wb.q(1)[slot] = r1; wb.q(2)[slot] = r2; wb.q(3)[slot] = r3; wb.q(4)[slot] = r4;
                 wb.tm[slot] = (uint16_t)tm;
             }
             if (fill + c > 64) { carry_tm = take ? 0u : tm; carry_id = id; carry_base = cbase; carry = true; fill = 64; break; }
@@ -307,11 +318,11 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
         if (fill == 0) break;  // list exhausted
         wave_lds_sync();
         // the sixteen group queues: slot numbers of the splats whose bit r is set, in slot (= depth) order, ended by 255
-        reinterpret_cast<uint4*>(&wb.ql[0][0])[lane] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        reinterpret_cast<uint4*>(&wb.ql[0][0])[lane] = make_uint4(0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u);
         // groups whose four pixels are all finished (saturated, or outside the image) take no more splats: their queues stay
         // empty from this batch on, so the batch's trip count is the longest queue among the groups still at work
         // (scripts/dev/group_trips.c: 719k -> 686k trips per frame on the bench scene, where every pixel saturates)
-        uint64_t dq = __ballot(done);
+        uint64_t dq = ballot64(done);
         dq &= dq >> 1; dq &= dq >> 2; dq &= 0x1111111111111111ull;            // bit 4g: group g is finished
         dq = (dq | (dq >> 3)) & 0x0303030303030303ull;                         // gather the sixteen bits ...
         dq = (dq | (dq >> 6)) & 0x000F000F000F000Full;
@@ -326,7 +337,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const bool in_r = ((nib >> r) & 1u) != 0u;
-            const uint64_t mr = __ballot(in_r);
+            const uint64_t mr = ballot64(in_r);
             if (in_r) wb.ql[r][rank_below(mr)] = (uint8_t)lane;
             trips = max(trips, (int)__popcll(mr));
         }
@@ -336,14 +347,14 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
         // entries one trip further ahead); unrolled by two with the two register sets swapping roles (no copies).
         int t = 0;
         uint32_t ja = qrow[0], jb = qrow[1];
-        float4 a0 = wb.q[0][ja & 63], a1 = wb.q[1][ja & 63], a2 = wb.q[2][ja & 63], a3 = wb.q[3][ja & 63], a4 = wb.q[4][ja & 63];
+        float4 a0 = wb.q(0)[ja], a1 = wb.q(1)[ja], a2 = wb.q(2)[ja], a3 = wb.q(3)[ja], a4 = wb.q(4)[ja];
         float4 b0, b1, b2, b3, b4;
 #define GS2D_FWD_STEP(C0, C1, C2, C3, C4, N0_, N1_, N2_, N3_, N4_, JN, JNN)                                          \
         {                                                                                                            \
             GS2D_PROF_TRIP();                                                                                        \
-            const bool live_ = JNN < 64u; /* JNN still holds THIS trip's queue entry; 255: this group's queue is exhausted */ \
-            N0_ = wb.q[0][JN & 63]; N1_ = wb.q[1][JN & 63]; N2_ = wb.q[2][JN & 63]; N3_ = wb.q[3][JN & 63];          \
-            N4_ = wb.q[4][JN & 63];                                                                                  \
+            const bool live_ = JNN < 64u; /* JNN still holds THIS trip's queue entry; 64: this group's queue is exhausted */ \
+            N0_ = wb.q(0)[JN]; N1_ = wb.q(1)[JN]; N2_ = wb.q(2)[JN]; N3_ = wb.q(3)[JN];                              \
+            N4_ = wb.q(4)[JN];                                                                                       \
             JNN = qrow[t + 2];                                                                                       \
             float alpha, depth;                                                                                      \
             bool ok;                                                                                                 \
@@ -380,7 +391,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                 T = test_T;                                                                                          \
                 last_contributor = contributor;                                                                      \
             }                                                                                                        \
-            if (++t >= trips || __ballot(!done) == 0) break;                                                         \
+            if (++t >= trips || ballot64(!done) == 0) break;                                                         \
         }
         for (;;) {
             GS2D_FWD_STEP(a0, a1, a2, a3, a4, b0, b1, b2, b3, b4, jb, ja)
@@ -441,8 +452,10 @@ __device__ __forceinline__ float reduce16_row(const float v[16], int lane)
     // Levels 1 and 2 pair lanes across DPP banks (l <-> 15-l flips bit 3, l <-> l^7 flips bit 2), so "lanes with the bit
     // set keep the odd value" is a bank mask: sum the even value on all lanes, then overwrite banks {2,3} (resp. {1,3})
     // with the sum of the odd value -- two DPP adds per output and no selects.  Same operands and order as
-    // keep + partner(give), so the sums are bit-identical.  (s_nop: VALU write -> DPP read needs 2 wait states and the
-    // compiler does not look inside asm blocks.)
+    // keep + partner(give), so the sums are bit-identical.  (s_nop at the start: VALU write -> DPP read of the same register
+    // needs 2 wait states and the compiler does not look inside asm blocks.  None is needed between or behind the blocks: a
+    // level's last two writes are read by the next level's third instruction or later, and what follows the second block are
+    // plain VALU reads, for which the compiler keeps its own hazard bookkeeping.)
     float e0, e1, e2, e3, e4, e5, e6, e7, f0, f1, f2, f3;
     asm("s_nop 1\n\t"
         "v_add_f32_dpp %0, %8, %8 row_mirror row_mask:0xf bank_mask:0xf\n\t"
@@ -460,8 +473,7 @@ __device__ __forceinline__ float reduce16_row(const float v[16], int lane)
         "v_add_f32_dpp %4, %17, %17 row_mirror row_mask:0xf bank_mask:0xc\n\t"
         "v_add_f32_dpp %5, %19, %19 row_mirror row_mask:0xf bank_mask:0xc\n\t"
         "v_add_f32_dpp %6, %21, %21 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %7, %23, %23 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-        "s_nop 1"
+        "v_add_f32_dpp %7, %23, %23 row_mirror row_mask:0xf bank_mask:0xc"
         : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(e4), "=&v"(e5), "=&v"(e6), "=&v"(e7)
         : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]),
           "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
@@ -472,8 +484,7 @@ __device__ __forceinline__ float reduce16_row(const float v[16], int lane)
         "v_add_f32_dpp %0, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
         "v_add_f32_dpp %1, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
         "v_add_f32_dpp %2, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %3, %11, %11 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-        "s_nop 1"
+        "v_add_f32_dpp %3, %11, %11 row_half_mirror row_mask:0xf bank_mask:0xa"
         : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3)
         : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(e4), "v"(e5), "v"(e6), "v"(e7));
     const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
@@ -498,8 +509,7 @@ __device__ __forceinline__ float reduce16_row_z(const float v[16], int lane)
         "v_add_f32_dpp %2, %12, %12 row_mirror row_mask:0xf bank_mask:0xc\n\t"
         "v_add_f32_dpp %3, %14, %14 row_mirror row_mask:0xf bank_mask:0xc\n\t"
         "v_add_f32_dpp %4, %16, %16 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %5, %18, %18 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-        "s_nop 1"
+        "v_add_f32_dpp %5, %18, %18 row_mirror row_mask:0xf bank_mask:0xc"
         : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(e4), "=&v"(e5), "=&v"(e7)
         : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]),
           "v"(v[10]), "v"(v[11]), "v"(v[15]));
@@ -511,8 +521,7 @@ __device__ __forceinline__ float reduce16_row_z(const float v[16], int lane)
         "v_add_f32_dpp %3, %10, %10 row_half_mirror row_mask:0xf bank_mask:0x8\n\t"  /* lanes 12-15 <- value 15 */
         "v_add_f32_dpp %0, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
         "v_add_f32_dpp %1, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %2, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-        "s_nop 1"
+        "v_add_f32_dpp %2, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xa"
         : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3)
         : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(e4), "v"(e5), "v"(e7));
     const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
@@ -564,50 +573,36 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
 // the accumulator at the end of the trip (0.338 ms, the latency enters the dependency chain), merging twin rows' totals
 // with v_permlane16/32_swap so that no trip needs the atomic (0.330 ms, +4 spills), and a per-row instead of
 // wave-uniform fallback (no change).
-// min over the six pairs of a ^ b: 0 iff two of the four (wave-uniform) values are equal.  Scalar unit only -- written out
-// because the compiler finishes the plain C++ form with v_mov / v_min3_u32 / v_cmp on the vector unit, the backward's
-// bottleneck.
-__device__ __forceinline__ uint32_t least_pair_xor(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
-{
-    uint32_t m, t;
-    asm("s_xor_b32 %0, %2, %3\n\t"
-        "s_xor_b32 %1, %2, %4\n\t"
-        "s_min_u32 %0, %0, %1\n\t"
-        "s_xor_b32 %1, %2, %5\n\t"
-        "s_min_u32 %0, %0, %1\n\t"
-        "s_xor_b32 %1, %3, %4\n\t"
-        "s_min_u32 %0, %0, %1\n\t"
-        "s_xor_b32 %1, %3, %5\n\t"
-        "s_min_u32 %0, %0, %1\n\t"
-        "s_xor_b32 %1, %4, %5\n\t"
-        "s_min_u32 %0, %0, %1"
-        : "=&s"(m), "=&s"(t)
-        : "s"(a), "s"(b), "s"(c), "s"(d)
-        : "scc");
-    return m;
-}
 #define GS2D_BWD_ACC_PRE(JJ)                                                                                            \
-    const int ai_ = ((JJ) & 63) * NACC + (acc_comp < 0 ? 0 : acc_comp);                                                 \
-    const float acc_old_ = wb.acc[ai_];                                                                                 \
-    const uint32_t ja_ = __builtin_amdgcn_readlane(JJ, 0), jb_ = __builtin_amdgcn_readlane(JJ, 16),                     \
-                   jc_ = __builtin_amdgcn_readlane(JJ, 32), jd_ = __builtin_amdgcn_readlane(JJ, 48);                    \
-    /* an exhausted row reads its own end marker (252 + row), so two of those never look like a shared splat */         \
-    const bool clash_ = least_pair_xor(ja_, jb_, jc_, jd_) == 0u;
+    const int ai_ = (JJ) * NACC + (acc_comp < 0 ? 0 : acc_comp);                                                 \
+    const float acc_old_ = wb.acc()[ai_];                                                                                 \
+    /* do two rows hold the same splat in this trip?  Decided for all trips of the batch at once when the queues are    \
+       built (clash_mask, one bit per trip): one scalar bit test here instead of four v_readlane + a scalar compare     \
+       chain per trip */                                                                                                \
+    const bool clash_ = ((clash_mask >> t) & 1ull) != 0ull;
 #ifndef GS2D_BWD_LDS_ACCUM  // (gs2d_blend_dev.h may have replaced it in an experiment build)
 #define GS2D_BWD_LDS_ACCUM(JJ, V)                                                                                       \
     if ((V) != 0.f) {                                                                                                   \
-        if (clash_) atomicAdd(&wb.acc[ai_], V);                                                                         \
-        else wb.acc[ai_] = acc_old_ + (V);                                                                              \
+        if (clash_) atomicAdd(&wb.acc()[ai_], V);                                                                         \
+        else wb.acc()[ai_] = acc_old_ + (V);                                                                              \
     }
 #endif
 #define GS2D_ACC 13
 #define GS2D_ACC_DET 18
 template <int NACC>
 struct BwdBatchT {
-    float4 q[4][64];
-    float acc[64 * NACC];
-    uint32_t pn[64];    // list position << 4 | cull bits of the staged splat
-    uint8_t ql[4][64];  // per-row queues: slot numbers, deepest first
+    // Entries past a queue's end hold slot 63 -- the deepest staged splat, always a real record -- and a row is live while the
+    // trip number is below its queue length: an exhausted row evaluates a real (finite) record with all its lanes inactive,
+    // so its sums are exact zeros and nothing is accumulated, and no access masks the slot number.  (Tried on the way: a
+    // marker of 64 read unmasked.  With a zeroed dummy 65th slot the extra 512 B of LDS per workgroup cost a fifth workgroup
+    // per CU, 0.385 instead of 0.273 ms; without one the row "blends" whatever words follow the arrays, 0 x Inf = NaN passes the
+    // `!= 0` test of the accumulate and lands behind the accumulator array -- a corrupted Gaussian id and a memory fault in
+    // the flush, caught by tests/test_gpu_batch.py.)
+    float raw[4 * 64 * 4 + 64 * NACC];  // q: 4 quarters x 64 slots x float4 (Tu|cx, Tv|cy, Tw|opacity, r g b position), then acc
+    uint32_t pn[64];    // Gaussian id | cull bits << 28 of the staged splat (read when queues are built and at the flush only)
+    __device__ __forceinline__ float4* q(int k) { return reinterpret_cast<float4*>(raw) + k * 64; }
+    __device__ __forceinline__ float* acc() { return raw + 4 * 64 * 4; }
+    uint8_t ql[4][64];  // per-row queues: slot numbers, deepest first, then 63s
     uint32_t tail[4];   // the pipeline reads up to two entries past a full queue (values unused)
 };
 
@@ -679,7 +674,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     }
     // Every gradient this wave produces is linear in its pixels' upstream gradients: a quadrant whose 64 pixels all
     // carry exact zeros (masked-out regions of the SLAM losses) contributes exactly nothing.
-    if (__ballot(dpx0 != 0.f || dpx1 != 0.f || dpx2 != 0.f || dL_ddepth != 0.f || dL_daccum != 0.f || dn0 != 0.f ||
+    if (ballot64(dpx0 != 0.f || dpx1 != 0.f || dpx2 != 0.f || dL_ddepth != 0.f || dL_daccum != 0.f || dn0 != 0.f ||
                  dn1 != 0.f || dn2 != 0.f || dL_dmedian_depth != 0.f || dL_dreg != 0.f) == 0)
         return;
     const float final_A = 1 - T_final;
@@ -717,11 +712,12 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     // LDS accumulator of this lane's slot; -1: normal component, added straight to the global record (not in DET: 13..15)
     const int acc_comp = slot < 12 ? slot : (slot == 15 ? 12 : (DET ? slot + 1 : -1));
 #pragma unroll
-    for (int i = 0; i < NACC; i++) wb.acc[i * 64 + lane] = 0.f;
+    for (int i = 0; i < NACC; i++) wb.acc()[i * 64 + lane] = 0.f;
+    if (lane < 4) wb.tail[lane] = 0x3F3F3F3Fu;
     // Wave-uniform data-dependent shortcut: when no pixel of this quadrant carries an upstream gradient on the
     // normal channels (SLAM's losses never touch them unless use_normal_loss), everything that only feeds
     // dL_dnormal / the normal term of dL_dalpha is exactly zero and is skipped.  Results are unchanged.
-    const bool any_dn = __ballot(dn0 != 0.f || dn1 != 0.f || dn2 != 0.f) != 0;
+    const bool any_dn = ballot64(dn0 != 0.f || dn1 != 0.f || dn2 != 0.f) != 0;
     // Batches are COMPACTED: the list is read in 64-instance chunks (back to front), but only the splats whose cull bits
     // (stored by the forward) touch this quadrant are staged, and chunks keep being added until all 64 LDS slots are in
     // use (a chunk that does not fit is split: its shallower part is carried into the next batch).  Compared with
@@ -774,7 +770,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                 my_id = point_list[at];  // unconditional and coalesced: issued together with the cull bits
 #endif
             }
-            const uint64_t tb = __ballot(tm != 0u);
+            const uint64_t tb = ballot64(tm != 0u);
             const int c = __popcll(tb);
             if (c == 0) continue;
             // deepest touched lane -> highest free slot: touched lanes above me = c - 1 - (touched lanes below me)
@@ -786,9 +782,9 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                 const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
                 const float red = rp[3].w;
                 const float4 r4 = rp[4];
-                wb.q[0][slot] = r0; wb.q[1][slot] = r1; wb.q[2][slot] = r2;
-                wb.q[3][slot] = make_float4(red, r4.x, r4.y, __uint_as_float(my_id));  // colour + the Gaussian id
-                wb.pn[slot] = (pos << 4) | tm;                                         // list position + cull bits
+                wb.q(0)[slot] = r0; wb.q(1)[slot] = r1; wb.q(2)[slot] = r2;
+                wb.q(3)[slot] = make_float4(red, r4.x, r4.y, __uint_as_float(pos));  // colour + the list position
+                wb.pn[slot] = my_id | (tm << 28);                                    // Gaussian id (< 2^28, checked by the API) + cull bits
             }
             if (fill + c > 64) { carry_tm = take ? 0u : tm; carry_id = my_id; carry_chunk = cb; fill = 64; break; }
             fill += c;
@@ -798,39 +794,49 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
         wave_lds_sync();
         // four depth-ordered queues, one per 4x4 sub-block (= DPP row): byte lists of slot numbers, deepest (= highest
         // slot) first, so walking a list front to back visits the row's splats back to front
-        uint32_t nib = lane >= 64 - fill ? wb.pn[lane] : 0u;
+        uint32_t nib = lane >= 64 - fill ? wb.pn[lane] >> 28 : 0u;
 #ifndef GS2D_NO_ROW_LAST  // dev A/B switch (scripts/dev/variants.sh)
         {   // row r keeps the splat only if it lies in front of the row's deepest contributor (pos < row_last_r)
-            const uint32_t pos = nib >> 4;
+            const uint32_t pos = __float_as_uint(wb.q(3)[lane].w);
             nib &= (pos < row_last0 ? 1u : 0u) | (pos < row_last1 ? 2u : 0u) | (pos < row_last2 ? 4u : 0u) | (pos < row_last3 ? 8u : 0u);
         }
 #endif
-        const uint64_t m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u), m2 = __ballot(nib & 4u), m3 = __ballot(nib & 8u);
+        const uint64_t m0 = ballot64(nib & 1u), m1 = ballot64(nib & 2u), m2 = ballot64(nib & 4u), m3 = ballot64(nib & 8u);
         const int len0 = __popcll(m0), len1 = __popcll(m1), len2 = __popcll(m2), len3 = __popcll(m3);
-        // every entry past a queue's end reads 252 + row = "exhausted" (any value >= 64; distinct per row for the
-        // shared-splat test of GS2D_BWD_ACC_PRE)
-        reinterpret_cast<uint32_t*>(wb.ql)[lane] = 0x01010101u * (0xFCu | (uint32_t)(lane >> 4));
+        // every entry past a queue's end reads slot 63 (see BwdBatchT)
+        reinterpret_cast<uint32_t*>(wb.ql)[lane] = 0x3F3F3F3Fu;
+        const int mylen = row_select(row8, len0, len1, len2, len3);  // this lane's row is live in trips 0 .. mylen - 1
         if (nib & 1u) wb.ql[0][len0 - 1 - rank_below(m0)] = (uint8_t)lane;
         if (nib & 2u) wb.ql[1][len1 - 1 - rank_below(m1)] = (uint8_t)lane;
         if (nib & 4u) wb.ql[2][len2 - 1 - rank_below(m2)] = (uint8_t)lane;
         if (nib & 8u) wb.ql[3][len3 - 1 - rank_below(m3)] = (uint8_t)lane;
         const int trips = max(max(len0, len1), max(len2, len3));  // (0: nothing staged lies in front of its rows' deepest contributors -- one idle step)
         wave_lds_sync();
+        // bit t: in trip t two LIVE rows hold the same splat: their totals then meet on one accumulator -- LDS atomic instead of
+        // the plain store, GS2D_BWD_LDS_ACCUM
+        uint64_t clash_mask;
+        {
+            const uint32_t qa = wb.ql[0][lane], qb = wb.ql[1][lane], qc = wb.ql[2][lane], qd = wb.ql[3][lane];
+            const bool la = lane < len0, lb = lane < len1, lc = lane < len2, ld = lane < len3;
+            clash_mask = ballot64((la && ((lb && qa == qb) || (lc && qa == qc) || (ld && qa == qd))) ||
+                                  (lb && ((lc && qb == qc) || (ld && qb == qd))) || (lc && ld && qc == qd));
+        }
         GS2D_PROF_STAGE_END();
         // software pipeline: queue entries are read two trips ahead, records one trip ahead
         int t = 0;
         uint32_t j = qrow[0], jx = qrow[1];
-        float4 ga0 = wb.q[0][j & 63], ga1 = wb.q[1][j & 63], ga2 = wb.q[2][j & 63];
+        float4 ga0 = wb.q(0)[j], ga1 = wb.q(1)[j], ga2 = wb.q(2)[j];
         float4 gb0, gb1, gb2;
 #define GS2D_BWD_STEP(G0, G1, G2, J, N0_, N1_, N2_, JN)                                                                  \
         {                                                                                                             \
             GS2D_PROF_TRIP();                                                                                         \
-            const uint32_t jnn = qrow[t + 2];                                                                         \
-            N0_ = wb.q[0][JN & 63]; N1_ = wb.q[1][JN & 63]; N2_ = wb.q[2][JN & 63];                                   \
-            const float4 cc = wb.q[3][J & 63]; /* r, g, b, id */                                                      \
-            const uint32_t contributor = wb.pn[J & 63] >> 4; /* list position, 0-based, as in backward.cu:285 */      \
-            bool active = J < 64u && contributor < last_contributor; /* J >= 252: queue exhausted; outside: last = 0 */ \
-            if (__ballot(active) != 0) {                                                                              \
+            uint32_t jnn = qrow[t + 2];                                                                               \
+            asm volatile("" : "+v"(jnn)); /* a full 32-bit value from here on: ds_read_u8 zero-extends, no v_and 0xff later */ \
+            N0_ = wb.q(0)[JN]; N1_ = wb.q(1)[JN]; N2_ = wb.q(2)[JN];                                                  \
+            const float4 cc = wb.q(3)[J]; /* r, g, b, list position */                                                \
+            const uint32_t contributor = __float_as_uint(cc.w); /* 0-based, as in backward.cu:285 */                  \
+            bool active = t < mylen && contributor < last_contributor; /* past its queue's end the row idles; outside: last = 0 */ \
+            if (ballot64(active) != 0) {                                                                              \
                 GS2D_BWD_ACC_PRE(J)                                                                                   \
                 /* Part A (all lanes): same geometry / alpha as the forward */                                        \
                 const float k0 = fmaf(pxf, G2.x, -G0.x), k1 = fmaf(pxf, G2.y, -G0.y), k2 = fmaf(pxf, G2.z, -G0.z);    \
@@ -894,7 +900,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                     last_depth = c_d;                                                                                 \
                     dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);                                    \
                     if (ANY_DN) { /* backward.cu:392-397; the normal is not staged: rare path, read it from the record */ \
-                        const float4 nn = rec[(size_t)__float_as_uint(cc.w) * GS2D_REC_F4 + 3];                       \
+                        const float4 nn = rec[(size_t)(wb.pn[J] & 0x0FFFFFFFu) * GS2D_REC_F4 + 3];                       \
                         an0 = fmaf(last_alpha, ln0, (1.f - last_alpha) * an0); ln0 = nn.x;                            \
                         dL_dalpha = fmaf(nn.x - an0, dn0, dL_dalpha);                                                 \
                         an1 = fmaf(last_alpha, ln1, (1.f - last_alpha) * an1); ln1 = nn.y;                            \
@@ -914,7 +920,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                     d_zl = ray ? 0.f : dL_dz;                              /* backward.cu:450-457 */                  \
                     d_t = ray ? 0.f : dL_dG * (-G * GS2D_FILTER_INV_SQ);                                              \
                 }                                                                                                     \
-                if (__ballot(active) != 0) {                                                                          \
+                if (ballot64(active) != 0) {                                                                          \
                     float g[16];                                                                                      \
                     g[0] = d_w * dpx0; g[1] = d_w * dpx1; g[2] = d_w * dpx2;                                          \
                     const float dL_ds0 = fmaf(d_gG, s0, d_zr * G2.x);                                                 \
@@ -943,21 +949,21 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                     /* LDS float atomics run at a few lanes per clock: rows/components that sum to +-0 skip them */    \
                     if (DET) { /* one row at a time: lanes of different rows may hold the same (splat, component) */ \
                         _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++)                                              \
-                            if (row == r_ && acc_comp >= 0 && tot != 0.f) wb.acc[(J & 63) * NACC + acc_comp] += tot; \
+                            if (row == r_ && acc_comp >= 0 && tot != 0.f) wb.acc()[J * NACC + acc_comp] += tot;        \
                     } else if (acc_comp >= 0) {                                                                       \
                         GS2D_BWD_LDS_ACCUM(J, tot)                                                                    \
                     } else if (ANY_DN && tot != 0.f)                                                                  \
-                        atomicAdd(grad_rec + (size_t)__float_as_uint(cc.w) * GS2D_GRAD_FLOATS + (slot - 9), tot);     \
-                    if (__ballot(d_t != 0.f) != 0) {                                                                  \
+                        atomicAdd(grad_rec + (size_t)(wb.pn[J] & 0x0FFFFFFFu) * GS2D_GRAD_FLOATS + (slot - 9), tot); \
+                    if (ballot64(d_t != 0.f) != 0) {                                                                  \
                         const float g_mx = row_sum_to_lane15(d_t * d0);                                               \
                         const float g_my = row_sum_to_lane15(d_t * d1);                                               \
                         if (DET) {                                                                                    \
                             _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++)                                          \
                                 if (row == r_ && li == 15 && (g_mx != 0.f || g_my != 0.f)) {                          \
-                                    wb.acc[(J & 63) * NACC + 16] += g_mx; wb.acc[(J & 63) * NACC + 17] += g_my;   \
+                                    wb.acc()[J * NACC + 16] += g_mx; wb.acc()[J * NACC + 17] += g_my;                   \
                                 }                                                                                     \
                         } else if (li == 15 && (g_mx != 0.f || g_my != 0.f)) {                                        \
-                            float* dst = grad_rec + (size_t)__float_as_uint(cc.w) * GS2D_GRAD_FLOATS;                 \
+                            float* dst = grad_rec + (size_t)(wb.pn[J] & 0x0FFFFFFFu) * GS2D_GRAD_FLOATS;         \
                             atomicAdd(dst + 16, g_mx); atomicAdd(dst + 17, g_my);                                     \
                         }                                                                                             \
                     }                                                                                                 \
@@ -987,13 +993,13 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
             for (int f0 = 64 - fill; f0 < 64; f0 += 4) {
                 const int fa = f0 + row;
                 if (fa < 64) {
-                    float* dst = det_slots + ((size_t)(range.x + (wb.pn[fa] >> 4)) * 4 + wave) * GS2D_GRAD_FLOATS;
+                    float* dst = det_slots + ((size_t)(range.x + __float_as_uint(wb.q(3)[fa].w)) * 4 + wave) * GS2D_GRAD_FLOATS;
 #pragma unroll
                     for (int c = li; c < NACC; c += 16) {
                         // accumulator c -> offset in the record: 0-2 colour, 3-11 dT, 12 opacity, 13-15 normal, 16-17 mean2D
                         const int off = c < 3 ? c : (c < 12 ? c + 3 : (c == 12 ? 15 : (c < 16 ? c - 10 : c)));
-                        dst[off] = wb.acc[fa * NACC + c];
-                        wb.acc[fa * NACC + c] = 0.f;
+                        dst[off] = wb.acc()[fa * NACC + c];
+                        wb.acc()[fa * NACC + c] = 0.f;
                     }
                 }
             }
@@ -1002,10 +1008,10 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
         const bool flush_lane = li < GS2D_ACC;
         for (int f0 = 64 - fill; GS2D_EXP_FLUSH(f0 < 64); f0 += 8) {
             const int fa = f0 + row, fb = f0 + 4 + row;  // slots >= 64 do not exist
-            float* pa = &wb.acc[(fa & 63) * GS2D_ACC + (flush_lane ? li : 0)];
-            float* pb = &wb.acc[(fb & 63) * GS2D_ACC + (flush_lane ? li : 0)];
+            float* pa = &wb.acc()[(fa & 63) * GS2D_ACC + (flush_lane ? li : 0)];
+            float* pb = &wb.acc()[(fb & 63) * GS2D_ACC + (flush_lane ? li : 0)];
             const float va = *pa, vb = *pb;
-            const uint32_t ida = __float_as_uint(wb.q[3][fa & 63].w), idb = __float_as_uint(wb.q[3][fb & 63].w);
+            const uint32_t ida = wb.pn[fa & 63] & 0x0FFFFFFFu, idb = wb.pn[fb & 63] & 0x0FFFFFFFu;
             if (fa < 64 && flush_lane && va != 0.f) {
                 *pa = 0.f;
                 GS2D_EXP_ATOMIC(atomicAdd(grad_rec + (size_t)ida * GS2D_GRAD_FLOATS + flush_off, va);)

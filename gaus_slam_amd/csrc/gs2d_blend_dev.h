@@ -47,5 +47,5 @@ __device__ unsigned long long g_wave_prof[2][4 * 8192 * 4];
 #endif
 
 #ifdef GS2D_EXPERIMENT
-#define GS2D_BWD_LDS_ACCUM(JJ, V) if ((V) != 0.f) GS2D_EXP_LDSADD(&wb.acc[((JJ) & 63) * NACC + acc_comp], V);
+#define GS2D_BWD_LDS_ACCUM(JJ, V) if ((V) != 0.f) GS2D_EXP_LDSADD(&wb.acc()[((JJ) & 63) * NACC + acc_comp], V);
 #endif

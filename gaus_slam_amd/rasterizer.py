@@ -435,6 +435,11 @@ def _take_sink():
     return _SINK.views, _SINK.chunk_rows, _SINK.on_chunk
 
 
+def _cpu_copy(args):
+    """Host copies of the tensor arguments (the reference's cpu_deep_copy_tuple, RAST/gaus_2dgs_rasterization/__init__.py:17-19)."""
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     """RAST/gaus_2dgs_rasterization/__init__.py:44-161."""
 
@@ -442,10 +447,19 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings):
         rs = raster_settings
-        num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_gaussians(
-            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
-            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
-            rs.campos, rs.use_sa, rs.prefiltered, rs.debug)
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
+                rs.campos, rs.use_sa, rs.prefiltered, rs.debug)
+        if rs.debug:  # RAST/gaus_2dgs_rasterization/__init__.py:84-91: keep a host copy of the arguments, dump it if the call fails
+            cpu_args = _cpu_copy(args)
+            try:
+                num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_gaussians(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+        else:
+            num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_gaussians(*args)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
@@ -467,12 +481,22 @@ class _RasterizeGaussians(torch.autograd.Function):
         if grad_depth is None:
             grad_depth = torch.zeros(ctx.image_shape[1], dtype=torch.float32, device=means3D.device)
         sink, chunk_rows, on_chunk = _take_sink()  # one backward per sink; a second one raises
+        args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+                rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, sh, rs.sh_degree, rs.campos, geomBuffer,
+                ctx.num_rendered, binningBuffer, imgBuffer, rs.use_sa, rs.debug)
+        kw = dict(grad_sink=sink, lean=True, chunk_rows=chunk_rows, on_chunk=on_chunk)
+        if rs.debug:  # RAST/gaus_2dgs_rasterization/__init__.py:135-142
+            cpu_args = _cpu_copy(args)
+            try:
+                res = rasterize_gaussians_backward(*args, **kw)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise ex
+        else:
+            res = rasterize_gaussians_backward(*args, **kw)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-         grad_rotations) = rasterize_gaussians_backward(
-            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
-            rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, sh, rs.sh_degree, rs.campos, geomBuffer,
-            ctx.num_rendered, binningBuffer, imgBuffer, rs.use_sa, rs.debug, grad_sink=sink, lean=True,
-            chunk_rows=chunk_rows, on_chunk=on_chunk)
+         grad_rotations) = res
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
                 grad_cov3Ds_precomp, None)
 

@@ -164,3 +164,20 @@ def test_deterministic_backward_refuses_chunks_without_a_forward_record(hiplib):
         assert b"without a forward record" in hiplib.gs2d_last_error()
     finally:
         hiplib.gs2d_set_deterministic(0)
+
+
+def test_debug_mode_dumps_the_arguments_of_a_failing_call(tmp_path, monkeypatch):
+    """debug=True mirrors RAST/gaus_2dgs_rasterization/__init__.py:84-91: a host copy of the arguments is taken before the
+    call and written to snapshot_fw.dump when the call raises (here: CPU tensors, rejected like the reference's CHECK_INPUT)."""
+    from gaus_slam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    monkeypatch.chdir(tmp_path)
+    P = 5
+    rs = GaussianRasterizationSettings(image_height=16, image_width=16, tanfovx=1.0, tanfovy=1.0, bg=torch.zeros(3), scale_modifier=1.0,
+                                       viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=0, campos=torch.zeros(3),
+                                       use_sa=True, prefiltered=False, debug=True)
+    means = torch.rand(P, 3)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        GaussianRasterizer(rs)(means, torch.zeros(P, 3), torch.rand(P, 1), colors_precomp=torch.rand(P, 3), scales=torch.rand(P, 2),
+                               rotations=torch.rand(P, 4))
+    dump = torch.load(tmp_path / "snapshot_fw.dump", weights_only=True)
+    assert torch.equal(dump[1], means) and dump[-1] is True
