@@ -37,11 +37,16 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 __device__ __forceinline__ float fast_exp_neg_half(float r) { return __builtin_amdgcn_exp2f(r * -0.72134752044448170368f); }
 __device__ __forceinline__ float fast_exp_neg_quarter(float q) { return __builtin_amdgcn_exp2f(q * -0.36067376022224085184f); }
 
+// Lane mask of a predicate.  The ballot builtin takes the predicate as a bool, so a test like `ballot64(x) != 0` compiles to a
+// scalar compare of the mask the v_cmp already produced; hip's __ballot(int) goes through an integer compare of a materialised
+// 0/1 (v_cndmask + v_cmp on the vector unit in every trip of both blend loops).
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // Part A of the per-(pixel, splat) work: ray-splat intersection and alpha (forward.cu:360-387; FMA form identical
-// to oracle/gs2d_oracle.c).  Branch-free; `ok` folds the reference's skip tests in their original order
+// to oracle/gs2d_oracle.c).  Branch-free; `ok_m` (a wave mask) folds the reference's skip tests in their original order
 // (p.z == 0, depth < near, power > 0, alpha < 1/255).
 __device__ __forceinline__ void fwd_eval(const float4 q0, const float4 q1, const float4 q2, float pxf, float pyf,
-                                         float& alpha, float& depth, bool& ok)
+                                         float& alpha, float& depth, uint64_t& ok_m)
 {
     const float k0 = fmaf(pxf, q2.x, -q0.x), k1 = fmaf(pxf, q2.y, -q0.y), k2 = fmaf(pxf, q2.z, -q0.z);
     const float l0 = fmaf(pyf, q2.x, -q1.x), l1 = fmaf(pyf, q2.y, -q1.y), l2 = fmaf(pyf, q2.z, -q1.z);
@@ -57,13 +62,10 @@ __device__ __forceinline__ void fwd_eval(const float4 q0, const float4 q1, const
     depth = (rho3d <= rho2d) ? fmaf(s0, q2.x, fmaf(s1, q2.y, q2.z)) : q2.z;
     alpha = fminf(0.99f, q2.w * fast_exp_neg_half(rho));
     // power = -0.5 rho > 0  <=>  rho < 0
-    ok = !(p2 == 0.0f) && !(depth < GS2D_NEAR_N) && !(rho < 0.0f) && !(alpha < 1.0f / 255.0f);
+    // (one ballot per comparison, combined on the scalar unit: the ballot of a compound predicate goes through v_cndmask 0/1 +
+    // v_cmp_ne, the ballot of a single comparison IS the comparison)
+    ok_m = ballot64(!(p2 == 0.0f)) & ballot64(!(depth < GS2D_NEAR_N)) & ballot64(!(rho < 0.0f)) & ballot64(!(alpha < 1.0f / 255.0f));
 }
-
-// Lane mask of a predicate.  The ballot builtin takes the predicate as a bool, so a test like `ballot64(x) != 0` compiles to a
-// scalar compare of the mask the v_cmp already produced; hip's __ballot(int) goes through an integer compare of a materialised
-// 0/1 (v_cndmask + v_cmp on the vector unit in every trip of both blend loops).
-__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // Wave-private LDS: operations of one wave execute in order; the fence only stops the compiler from reordering them.
 __device__ __forceinline__ void wave_lds_sync()
@@ -267,7 +269,9 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     float Dp = 0.f, M1 = 0.f, M2 = 0.f, D2 = 0.f, distortion = 0.f, median_depth = 0.f;
     uint32_t median_contributor = 0;  // the reference keeps a float initialised to -1 and stores (uint) -> 0
     uint32_t last_contributor = 0;
-    bool done = !inside;
+    // "this pixel is finished" (outside the image, or saturated) as a WAVE MASK in a scalar register pair: a loop-carried bool
+    // is kept by the compiler as 0/1 in a vector register and turned back into a mask with v_cmp in every trip
+    uint64_t done_m = ballot64(!inside);
     GS2D_PROF_BEGIN();
 
     // Batches are COMPACTED: the list is read in 64-instance chunks, but only the splats whose cull bits touch this
@@ -282,7 +286,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     uint32_t pf_tm = hits16[(size_t)min(next_chunk + lane, last_i) * 4 + wave];
     uint32_t pf_id = point_list[min(next_chunk + lane, last_i)];
     for (;;) {
-        if (ballot64(!done) == 0) break;
+        if (~done_m == 0ull) break;
         prio_by_remaining<GS2D_FWD_PRIO_SHIFT>(range.y - min(next_chunk, range.y), range.y - range.x);
         int fill = 0;
         GS2D_PROF_STAGE_BEGIN();
@@ -322,7 +326,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
         // groups whose four pixels are all finished (saturated, or outside the image) take no more splats: their queues stay
         // empty from this batch on, so the batch's trip count is the longest queue among the groups still at work
         // (scripts/dev/group_trips.c: 719k -> 686k trips per frame on the bench scene, where every pixel saturates)
-        uint64_t dq = ballot64(done);
+        uint64_t dq = done_m;
         dq &= dq >> 1; dq &= dq >> 2; dq &= 0x1111111111111111ull;            // bit 4g: group g is finished
         dq = (dq | (dq >> 3)) & 0x0303030303030303ull;                         // gather the sixteen bits ...
         dq = (dq | (dq >> 6)) & 0x000F000F000F000Full;
@@ -357,13 +361,13 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
             N4_ = wb.q(4)[JN];                                                                                       \
             JNN = qrow[t + 2];                                                                                       \
             float alpha, depth;                                                                                      \
-            bool ok;                                                                                                 \
-            fwd_eval(C0, C1, C2, pxf, pyf, alpha, depth, ok);                                                        \
+            uint64_t ok_m;                                                                                           \
+            fwd_eval(C0, C1, C2, pxf, pyf, alpha, depth, ok_m);                                                      \
             const float test_T = T * (1 - alpha);                                                                    \
-            const bool pass = ok && !done && live_;                                                                  \
-            const bool stop = pass && test_T < 0.0001f;                                                              \
-            done = done || stop;                                                                                     \
-            if (pass && !stop) {                                                                                     \
+            const uint64_t pass_m = ok_m & ballot64(live_) & ~done_m;                                                \
+            const uint64_t stop_m = pass_m & ballot64(test_T < 0.0001f);                                             \
+            done_m |= stop_m;                                                                                        \
+            if (__builtin_amdgcn_inverse_ballot_w64(pass_m & ~stop_m)) {                                             \
                 const uint32_t contributor = __float_as_uint(C4.w) + 1u; /* list position + 1 */                    \
                 const float w = alpha * T;                                                                           \
                 if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }                            \
@@ -391,7 +395,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                 T = test_T;                                                                                          \
                 last_contributor = contributor;                                                                      \
             }                                                                                                        \
-            if (++t >= trips || ballot64(!done) == 0) break;                                                         \
+            if (++t >= trips || ~done_m == 0ull) break;                                                              \
         }
         for (;;) {
             GS2D_FWD_STEP(a0, a1, a2, a3, a4, b0, b1, b2, b3, b4, jb, ja)
@@ -586,6 +590,23 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
         if (clash_) atomicAdd(&wb.acc()[ai_], V);                                                                         \
         else wb.acc()[ai_] = acc_old_ + (V);                                                                              \
     }
+#endif
+// dev A/B switches (scripts/dev/variants.sh) for the wave-level "does any lane contribute?" shortcuts of the trip step.
+// Measured in round 3 (one session, two runs each): skipping the whole step when no lane can be active (a test on the freshly
+// loaded list position, BEFORE the geometry) costs more than it saves -- every trip waits for v_cmp -> SGPR -> s_cbranch
+// before its first FMA: 0.2745 -> 0.2665 ms without it (default now); the second shortcut, in front of the gradient expansion
+// and the butterfly, pays: 0.279 without it.  (Also tried, no gain: letting every live row store on clash-free trips so that
+// the store's lane mask does not depend on the butterfly's result, 0.267; announcing the rare low-pass branch by an early
+// ballot, 0.269.)
+#ifdef GS2D_BWD_EARLY_SKIP
+#define GS2D_BWD_SKIP1(X) (X)
+#else
+#define GS2D_BWD_SKIP1(X) true
+#endif
+#ifdef GS2D_BWD_NO_SKIP2
+#define GS2D_BWD_SKIP2(X) true
+#else
+#define GS2D_BWD_SKIP2(X) (X)
 #endif
 #define GS2D_ACC 13
 #define GS2D_ACC_DET 18
@@ -835,8 +856,9 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
             N0_ = wb.q(0)[JN]; N1_ = wb.q(1)[JN]; N2_ = wb.q(2)[JN];                                                  \
             const float4 cc = wb.q(3)[J]; /* r, g, b, list position */                                                \
             const uint32_t contributor = __float_as_uint(cc.w); /* 0-based, as in backward.cu:285 */                  \
-            bool active = t < mylen && contributor < last_contributor; /* past its queue's end the row idles; outside: last = 0 */ \
-            if (ballot64(active) != 0) {                                                                              \
+            /* "this lane contributes" as a wave mask in scalar registers (tests on it are scalar compares, not v_cndmask + v_cmp) */ \
+            uint64_t am = ballot64(t < mylen) & ballot64(contributor < last_contributor); /* past its queue's end the row idles; outside: last = 0 */ \
+            if (GS2D_BWD_SKIP1(am != 0ull)) {                                                                          \
                 GS2D_BWD_ACC_PRE(J)                                                                                   \
                 /* Part A (all lanes): same geometry / alpha as the forward */                                        \
                 const float k0 = fmaf(pxf, G2.x, -G0.x), k1 = fmaf(pxf, G2.y, -G0.y), k2 = fmaf(pxf, G2.z, -G0.z);    \
@@ -854,7 +876,8 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                 float c_d = ray ? fmaf(s0, G2.x, fmaf(s1, G2.y, G2.z)) : G2.z;                                        \
                 const float G = fast_exp_neg_half(rho);                                                               \
                 const float alpha = fminf(0.99f, G2.w * G);                                                           \
-                active = active && !(p2 == 0.0f) && !(c_d < GS2D_NEAR_N) && !(rho < 0.0f) && !(alpha < 1.0f / 255.0f); \
+                am &= ballot64(!(p2 == 0.0f)) & ballot64(!(c_d < GS2D_NEAR_N)) & ballot64(!(rho < 0.0f)) & ballot64(!(alpha < 1.0f / 255.0f)); \
+                const bool active = __builtin_amdgcn_inverse_ballot_w64(am);                                          \
                 /* Part B (contributing lanes only): state recurrences; it leaves six "drivers" from which every      \
                    gradient component follows linearly -- all zero for the lanes that do not contribute. */           \
                 float d_w = 0.f, d_gG = 0.f, d_zr = 0.f, d_zl = 0.f, d_t = 0.f, d_op = 0.f;                           \
@@ -920,7 +943,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                     d_zl = ray ? 0.f : dL_dz;                              /* backward.cu:450-457 */                  \
                     d_t = ray ? 0.f : dL_dG * (-G * GS2D_FILTER_INV_SQ);                                              \
                 }                                                                                                     \
-                if (ballot64(active) != 0) {                                                                          \
+                if (GS2D_BWD_SKIP2(am != 0ull)) {                                                                      \
                     float g[16];                                                                                      \
                     g[0] = d_w * dpx0; g[1] = d_w * dpx1; g[2] = d_w * dpx2;                                          \
                     const float dL_ds0 = fmaf(d_gG, s0, d_zr * G2.x);                                                 \

@@ -11,7 +11,7 @@ import sys
 
 d = sys.argv[1]
 STAGE = {"blend_fwd_kernel": "blend_fwd", "blend_bwd_kernel": "blend_bwd", "preprocess_fwd_kernel": "preprocess",
-         "preprocess_bwd_kernel": "preprocess_bwd", "bin_hist_kernel": "sort", "bin_scatter_kernel": "sort", "tile_depth_sort_kernel": "sort",
+         "preprocess_bwd_kernel": "preprocess_bwd", "bin_hist_kernel": "sort", "bin_row_scan_kernel": "sort", "bin_scatter_kernel": "sort", "tile_depth_sort_kernel": "sort",
          "scan_reduce_kernel": "sort", "scan_apply_kernel": "sort", "duplicate_kernel": "duplicate"}
 
 
@@ -33,7 +33,8 @@ for k, st in STAGE.items():
     traffic[st] += (2 * f + w) * 1024  # KB as reported -> bytes; FETCH_SIZE counts 64 B per 128-B request on gfx950
 out_t = {k: int(v) for k, v in traffic.items()}
 out_t["_note"] = ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes of `bench.py --steps 3`), "
-                  "FETCH_SIZE doubled per the gfx950 guide (MI355X_MICROARCH.md, HBM); sort = bin_hist + scans + bin_scatter + tile_depth_sort")
+                  "FETCH_SIZE doubled per the gfx950 guide (MI355X_MICROARCH.md, HBM) -- verified for 80-byte gathers as well, profiles/fetch_size_probe_r03.txt; "
+                  "sort = bin_hist + bin_row_scan + bin_scatter (+ tile_depth_sort when it runs as a kernel of its own; at the headline size it is a phase of blend_fwd)")
 out_v = {}
 for k in ("blend_fwd_kernel", "blend_bwd_kernel"):
     if k in sq:

@@ -15,7 +15,7 @@ d = sys.argv[1]
 def short(n):
     for k in ("blend_fwd_kernel", "blend_bwd_kernel", "preprocess_fwd_kernel", "preprocess_bwd_kernel", "radix_hist_kernel",
               "radix_scatter_kernel", "scan_reduce_kernel", "scan_blocksums_kernel", "scan_apply_kernel",
-              "duplicate_kernel", "tile_ranges_kernel", "tile_depth_sort_kernel", "bin_hist_kernel", "bin_scatter_kernel", "mark_visible_kernel", "knn_kernel",
+              "duplicate_kernel", "tile_ranges_kernel", "tile_depth_sort_kernel", "bin_hist_kernel", "bin_row_scan_kernel", "bin_scatter_kernel", "sum_frames_kernel", "mark_visible_kernel", "knn_kernel",
               "det_reduce_kernel", "det_inverse_kernel"):
         if k in n:
             return k
