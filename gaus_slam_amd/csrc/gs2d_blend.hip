@@ -78,9 +78,6 @@ __device__ __forceinline__ void wave_lds_sync()
 #ifndef GS2D_WAVES_PER_EU
 #define GS2D_WAVES_PER_EU 5  // 96 VGPRs: all 1200 tiles of a 640x480 frame resident at once (5 workgroups per CU)
 #endif
-#ifndef GS2D_BWD_PREFETCH
-#define GS2D_BWD_PREFETCH 0  // cull bits + ids one chunk ahead in the backward: measured neutral to slightly negative (registers)
-#endif
 #ifndef GS2D_FWD_WAVES_PER_EU
 #define GS2D_FWD_WAVES_PER_EU GS2D_WAVES_PER_EU
 #endif
@@ -127,6 +124,8 @@ struct FwdBatch {
     __device__ __forceinline__ float4* q(int k) { return qf + k * 64; }
     uint32_t tail[4];           // the pipeline reads up to two entries past a full queue (values unused)
     uint16_t tm[64];            // group bits of the staged splats
+    uint32_t sid[64];           // Gaussian id and list position of the staged splats: a batch's slots are handed out chunk by
+    uint32_t spos[64];          // chunk, its records are gathered in ONE round trip afterwards
 };
 
 // XCD-aware workgroup -> tile mapping.  Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own
@@ -280,11 +279,16 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     uint32_t next_chunk = range.x;  // absolute index of the next chunk to read
     uint32_t carry_base = 0, carry_tm = 0u, carry_id = 0u;
     bool carry = false;
-    // the cull bits and the Gaussian id of chunk `next_chunk` are always in flight one chunk ahead (unconditional loads,
-    // index clamped to the list), so that the record gather is the only serial memory round trip of a chunk
+    // Staging a batch costs ONE exposed memory round trip: the cull bits and Gaussian ids of the next TWO chunks are always in
+    // flight (unconditional loads, index clamped to the list), the chunk loop only hands out slots (id, position, bits -> LDS),
+    // and when the 64 slots are taken -- or the list ends -- lane l gathers the record of slot l.  (Until round 3 every chunk
+    // gathered its own records before the next chunk was looked at: about three dependent gathers per batch, 20 % of a
+    // forward wave's lifetime, scripts/dev/wave_profile.py.)
     const uint32_t last_i = range.y > range.x ? range.y - 1u : range.x;
     uint32_t pf_tm = hits16[(size_t)min(next_chunk + lane, last_i) * 4 + wave];
     uint32_t pf_id = point_list[min(next_chunk + lane, last_i)];
+    uint32_t pg_tm = hits16[(size_t)min(next_chunk + 64u + lane, last_i) * 4 + wave];
+    uint32_t pg_id = point_list[min(next_chunk + 64u + lane, last_i)];
     for (;;) {
         if (~done_m == 0ull) break;
         prio_by_remaining<GS2D_FWD_PRIO_SHIFT>(range.y - min(next_chunk, range.y), range.y - range.x);
@@ -299,8 +303,9 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                 cbase = next_chunk; next_chunk += 64;
                 tm = cbase + lane < range.y ? pf_tm : 0u;
                 id = pf_id;
-                pf_tm = hits16[(size_t)min(next_chunk + lane, last_i) * 4 + wave];
-                pf_id = point_list[min(next_chunk + lane, last_i)];
+                pf_tm = pg_tm; pf_id = pg_id;
+                pg_tm = hits16[(size_t)min(next_chunk + 64u + lane, last_i) * 4 + wave];
+                pg_id = point_list[min(next_chunk + 64u + lane, last_i)];
             }
             const uint64_t tb = ballot64(tm != 0u);
             const int c = __popcll(tb);
@@ -308,16 +313,22 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
             const int slot = fill + rank_below(tb);
             const bool take = tm != 0u && slot < 64;
             if (take) {
-                const float4* rp = rec + (size_t)id * GS2D_REC_F4;
-                const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
-                float4 r4 = rp[4];
-                r4.w = __uint_as_float(cbase - range.x + lane);  // the list position rides in the free slot
-                wb.q(0)[slot] = r0; wb.q(1)[slot] = r1; wb.q(2)[slot] = r2; wb.q(3)[slot] = r3; wb.q(4)[slot] = r4;
+                wb.sid[slot] = id;
+                wb.spos[slot] = cbase - range.x + lane;  // the list position rides in the record's free word
                 wb.tm[slot] = (uint16_t)tm;
             }
             if (fill + c > 64) { carry_tm = take ? 0u : tm; carry_id = id; carry_base = cbase; carry = true; fill = 64; break; }
             fill += c;
             if (fill == 64) break;
+        }
+        if (fill == 0) break;  // list exhausted
+        wave_lds_sync();
+        if (lane < fill) {
+            const float4* rp = rec + (size_t)wb.sid[lane] * GS2D_REC_F4;
+            const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+            float4 r4 = rp[4];
+            r4.w = __uint_as_float(wb.spos[lane]);
+            wb.q(0)[lane] = r0; wb.q(1)[lane] = r1; wb.q(2)[lane] = r2; wb.q(3)[lane] = r3; wb.q(4)[lane] = r4;
         }
         if (fill == 0) break;  // list exhausted
         wave_lds_sync();
@@ -756,20 +767,23 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     int chunk = (int)((max_last + 63) / 64) - 1;  // next chunk to read
     int carry_chunk = -1;                           // chunk whose shallower part is still waiting
     uint32_t carry_tm = 0u, carry_id = 0u;
-    // cull bits and Gaussian ids of chunk `chunk` are always in flight one chunk ahead (unconditional loads, index
-    // clamped to the part of the list that matters), so the record gather is a chunk's only serial memory round trip
-    // (issued when a chunk is consumed and again right after a trip loop -- before the flush -- rather than kept alive
-    // through the trip loop: those two registers would push the loop over its 96-VGPR budget.)
+    // Staging a batch costs TWO exposed memory round trips: the chunk loop only hands out slots (Gaussian id + cull bits -> pn,
+    // list position -> the record's free word) while the cull bits and ids of the NEXT chunk are already in flight, and when
+    // the 64 slots are taken -- or the list ends -- lane l gathers the record of slot l.  (Until round 3 every chunk loaded its
+    // bits and ids, waited, gathered its records, waited: about six dependent round trips per batch.)  The prefetch registers
+    // live inside the staging loop only -- kept across the trip loop they cost the loop a register it does not have.
     const uint32_t last_i = range.x + max_last - 1u;
-#if GS2D_BWD_PREFETCH
-    uint32_t pf_tm = hits[(size_t)min(range.x + (uint32_t)chunk * 64u + lane, last_i) * 4 + wave];
-    uint32_t pf_id = point_list[min(range.x + (uint32_t)chunk * 64u + lane, last_i)];
-#endif
     for (;;) {
         int fill = 0;
         prio_by_remaining<GS2D_BWD_PRIO_SHIFT>((uint32_t)(chunk + 1), (max_last + 63u) / 64u);
         GS2D_PROF_STAGE_BEGIN();
         wave_lds_sync();  // previous batch fully consumed before it is overwritten
+        uint32_t pf_tm = 0u, pf_id = 0u;
+        if (chunk >= 0) {
+            const uint32_t at = min(range.x + (uint32_t)chunk * 64u + lane, last_i);
+            pf_tm = hits[(size_t)at * 4 + wave];
+            pf_id = point_list[at];  // unconditional and coalesced: issued together with the cull bits
+        }
         for (;;) {
             uint32_t tm, my_id;
             int cb;
@@ -779,17 +793,11 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                 cb = chunk--;
                 const int n = (int)min(64u, max_last - (uint32_t)cb * 64u);
                 // queues come from the cull bits of this (instance, quadrant)
-#if GS2D_BWD_PREFETCH
                 tm = lane < n ? pf_tm : 0u;
                 my_id = pf_id;
-                const uint32_t nb = range.x + (uint32_t)max(chunk, 0) * 64u + lane;
-                pf_tm = hits[(size_t)min(nb, last_i) * 4 + wave];
-                pf_id = point_list[min(nb, last_i)];
-#else
-                const uint32_t at = min(range.x + (uint32_t)cb * 64u + lane, last_i);
-                tm = lane < n ? hits[(size_t)at * 4 + wave] : 0u;
-                my_id = point_list[at];  // unconditional and coalesced: issued together with the cull bits
-#endif
+                const uint32_t nb = min(range.x + (uint32_t)max(chunk, 0) * 64u + lane, last_i);
+                pf_tm = hits[(size_t)nb * 4 + wave];
+                pf_id = point_list[nb];
             }
             const uint64_t tb = ballot64(tm != 0u);
             const int c = __popcll(tb);
@@ -798,18 +806,23 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
             const int slot = 64 - fill - c + rank_below(tb);
             const bool take = tm != 0u && slot >= 0;
             if (take) {
-                const uint32_t pos = (uint32_t)cb * 64u + lane;
-                const float4* rp = rec + (size_t)my_id * GS2D_REC_F4;
-                const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-                const float red = rp[3].w;
-                const float4 r4 = rp[4];
-                wb.q(0)[slot] = r0; wb.q(1)[slot] = r1; wb.q(2)[slot] = r2;
-                wb.q(3)[slot] = make_float4(red, r4.x, r4.y, __uint_as_float(pos));  // colour + the list position
-                wb.pn[slot] = my_id | (tm << 28);                                    // Gaussian id (< 2^28, checked by the API) + cull bits
+                wb.q(3)[slot].w = __uint_as_float((uint32_t)cb * 64u + lane);  // the list position
+                wb.pn[slot] = my_id | (tm << 28);                             // Gaussian id (< 2^28, checked by the API) + cull bits
             }
             if (fill + c > 64) { carry_tm = take ? 0u : tm; carry_id = my_id; carry_chunk = cb; fill = 64; break; }
             fill += c;
             if (fill == 64) break;
+        }
+        if (fill == 0) break;  // list exhausted
+        wave_lds_sync();
+        if (lane >= 64 - fill) {
+            const float4* rp = rec + (size_t)(wb.pn[lane] & 0x0FFFFFFFu) * GS2D_REC_F4;
+            const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+            const float red = rp[3].w;
+            const float4 r4 = rp[4];
+            wb.q(0)[lane] = r0; wb.q(1)[lane] = r1; wb.q(2)[lane] = r2;
+            float* cw = reinterpret_cast<float*>(&wb.q(3)[lane]);
+            cw[0] = red; cw[1] = r4.x; cw[2] = r4.y;  // colour; the fourth word already holds the list position
         }
         if (fill == 0) break;  // list exhausted
         wave_lds_sync();
@@ -1000,15 +1013,6 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
             GS2D_BWD_STEP(gb0, gb1, gb2, jx, ga0, ga1, ga2, j)
         }
 #undef GS2D_BWD_STEP
-#if GS2D_BWD_PREFETCH
-        {   // re-issue the prefetch of the next chunk (see above; the opaque index keeps the compiler from reusing the copy
-            // it loaded before the trip loop, which would have to stay in registers through it)
-            uint32_t nb = range.x + (uint32_t)max(chunk, 0) * 64u + lane;
-            asm volatile("" : "+v"(nb));
-            pf_tm = hits[(size_t)min(nb, last_i) * 4 + wave];
-            pf_id = point_list[min(nb, last_i)];
-        }
-#endif
         // flush: every touched splat of the batch goes to its global record once, four splats (one per row) per pass
         // two passes (eight splats) per iteration so the LDS round trips of one pass hide behind the other
         if (DET) {

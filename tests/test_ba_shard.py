@@ -133,3 +133,29 @@ def test_second_backward_inside_one_grad_sink_raises():
         with rasterizer.grad_sink({}):
             with rasterizer.grad_sink({}):
                 pass
+
+
+def test_k_keyframe_schedule_and_batch_fn_is_a_gpu_path():
+    """ba_shard.k_keyframe_schedule: steps / K (rounded up), learning rates x K; a batch_fn is only used on CUDA parameters
+    (the batched operator call has no CPU form) -- on CPU the keyframes go through render_loss_fn one by one."""
+    from gaus_slam_amd import ba_shard
+    steps, lrs = ba_shard.k_keyframe_schedule(4, 1001, {"means3D": 1e-4, "colors": 2.5e-3})
+    assert steps == 251 and lrs == {"means3D": 4e-4, "colors": 1e-2}
+    assert ba_shard.k_keyframe_schedule(1, 7, {"a": 0.5}) == (7, {"a": 0.5})
+    P = 6
+    params = {n: torch.randn(P, k, requires_grad=True) for n, k in ba_shard.BUCKET_FIELDS.items()}
+    calls = []
+
+    def one(p, kf):
+        calls.append(("one", kf))
+        return sum((v * (kf + 1)).sum() for v in p.values())
+
+    def batch(p, kfs):
+        calls.append(("batch", tuple(kfs)))
+        return sum(one(p, k) for k in kfs)
+
+    ba = ba_shard.KeyframeShardedBA(params, one, batch_fn=batch)
+    g = ba.step([0, 1, 2])
+    assert [c[0] for c in calls] == ["one", "one", "one"]
+    for n, k in ba_shard.BUCKET_FIELDS.items():
+        assert torch.allclose(g[n], torch.full((P, k), 6.0))
