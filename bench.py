@@ -76,7 +76,7 @@ def latest_profile(stem):
 
 
 def main():
-    global PREWARM_STEPS, _ONE_RANK_RCCL, KEEP_GC
+    global PREWARM_STEPS, _ONE_RANK_RCCL
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -108,8 +108,6 @@ def main():
                     "not a performance number")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the cold-start leg (config.cold_value) and the "
                     "reference-binning leg (config.reference_binning_value)")
-    ap.add_argument("--keep-gc", action="store_true", help="leave Python's cyclic garbage collector enabled inside the warm-up + timed "
-                    "region (default: collected once, then disabled for that region, as timeit does)")
     ap.add_argument("--json-out", default=None, help="also write the JSON line to this file (profiles/...)")
     args = ap.parse_args()
 
@@ -126,7 +124,6 @@ def main():
         _bs.MIN_COLLECTIVE_WORLD = 1
         os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
     PREWARM_STEPS = max(0, args.prewarm_steps)
-    KEEP_GC = bool(args.keep_gc)
     # stdout carries exactly ONE line, the JSON: whatever libraries print on file descriptor 1 while the job runs (RCCL writes
     # a five-line version banner there when a communicator is created) goes to stderr instead
     sys.stdout.flush()
@@ -182,7 +179,6 @@ def _dist_on(world):
 PREWARM_STEPS = 3000    # upper bound
 PREWARM_SECONDS = 1.6   # target duration
 PREWARM_DONE = 0        # steps actually run (reported as config.prewarm_steps)
-KEEP_GC = False         # --keep-gc: leave Python's cyclic GC enabled inside the timed region
 
 
 def timed(one_step, steps, warmup, world, dev, prewarm=True):
@@ -216,26 +212,17 @@ def timed(one_step, steps, warmup, world, dev, prewarm=True):
             one_step()
         sync()
         PREWARM_DONE = n0 + n1
-    # The cyclic garbage collector stays out of the warm-up + timed region (as timeit does): a generation-2 pass over the
-    # process's objects takes milliseconds -- 10-20 % of a 20-step measurement when it happens to fall into it, and the idle gap
-    # it leaves on the stream also drops the card's clocks (see the pre-warm above).  --keep-gc leaves it on.
-    import gc
-    gc_was_on = gc.isenabled() and not KEEP_GC
-    if gc_was_on:
-        gc.collect()
-        gc.disable()
-    try:
-        for _ in range(warmup):
-            one_step()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            one_step()
-        sync()
-        elapsed = time.perf_counter() - t0
-    finally:
-        if gc_was_on:
-            gc.enable()
+    # (Tried in round 3: taking Python's cyclic garbage collector out of this region.  gc.disable() alone changes nothing --
+    # 2182 vs 2185 frames/s over six runs each -- and a gc.collect() in front of the warm-up costs 8 %: the tens of milliseconds it
+    # takes are an idle gap on the stream, the card drops its clocks and W = 5 warm-up steps do not bring them back.)
+    for _ in range(warmup):
+        one_step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
     if _dist_on(world):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -720,9 +720,15 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     const float tf_bg = T_final * (fmaf(bg[2], dpx2, fmaf(bg[1], dpx1, bg[0] * dpx0)) - dL_daccum);
     const float sa_k = 1.0f / (4 * fmaxf(mstd * (1.0f / (1 - T_final)), 1e-7f));  // per-pixel constant (IEEE, as the oracle)
     const float c1f = GS2D_FAR_N / (GS2D_FAR_N - GS2D_NEAR_N);
-    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
-    float last_depth = 0.f, ln0 = 0.f, ln1 = 0.f, ln2 = 0.f, accum_depth_rec = 0.f;
-    float an0 = 0.f, an1 = 0.f, an2 = 0.f, last_dL_dT = 0.f, last_alpha = 0.f;
+    // The reference keeps, per blended channel x (r, g, b, depth, normal xyz), the back-to-front blend accum_x of the values
+    // behind the current splat and adds (x - accum_x) * dL_dx to dL_dalpha (backward.cu:331-344, 380-397).  All channels are
+    // blended with the same weights, so the SUM over the channels obeys one scalar recurrence:
+    //     D = sum_x x * dL_dx  (this splat),   S <- last_alpha * D_prev + (1 - last_alpha) * S,   dL_dalpha += D - S
+    // and the regulariser's  dL_dweight - last_dL_dT  (backward.cu:353-373: last_dL_dT <- dL_dweight alpha + (1 - alpha)
+    // last_dL_dT, i.e. the same blend taken one splat later) is one more such channel with unit upstream gradient.
+    // Two registers (S, D_prev) and nine operations per trip instead of nine registers (fifteen with normals) and two dozen
+    // operations; the same sums in a different order (rounding-level deviation from the oracle's per-channel form)
+    float blend_S = 0.f, blend_Dprev = 0.f, last_alpha = 0.f;
 
     // nothing behind the deepest contributor of this quadrant can receive a gradient from it
     uint32_t max_last = last_contributor;
@@ -899,13 +905,8 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                     T = T * ioma;                                                                                     \
                     const float w = alpha * T;                                                                        \
                     float dL_dalpha = 0.0f;                                                                           \
-                    /* backward.cu:331-344 */                                                                         \
-                    ar0 = fmaf(last_alpha, lc0, (1.f - last_alpha) * ar0); lc0 = cc.x;                                \
-                    dL_dalpha = fmaf(cc.x - ar0, dpx0, dL_dalpha);                                                    \
-                    ar1 = fmaf(last_alpha, lc1, (1.f - last_alpha) * ar1); lc1 = cc.y;                                \
-                    dL_dalpha = fmaf(cc.y - ar1, dpx1, dL_dalpha);                                                    \
-                    ar2 = fmaf(last_alpha, lc2, (1.f - last_alpha) * ar2); lc2 = cc.z;                                \
-                    dL_dalpha = fmaf(cc.z - ar2, dpx2, dL_dalpha);                                                    \
+                    /* backward.cu:331-344: the colour part of D (see blend_S above) */                               \
+                    float D_ = fmaf(cc.z, dpx2, fmaf(cc.y, dpx1, cc.x * dpx0));                                       \
                     float conf = 1.f;                                                                                 \
                     if (USE_SA) { /* backward.cu:347-351 */                                                           \
                         if (T < 0.5f) {                                                                               \
@@ -918,32 +919,24 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                     if (contributor == median_contributor - 1u) dL_dz = dL_dmedian_depth;                             \
                     if (USE_SA) {                                                                                     \
                         const float dm = c_d - mm;                                                                    \
-                        dL_dweight = (dm * dm) * dL_dreg;                                                             \
-                        dL_dalpha += dL_dweight - last_dL_dT;                                                         \
-                        last_dL_dT = fmaf(dL_dweight, alpha, (1 - alpha) * last_dL_dT);                               \
+                        dL_dweight = (dm * dm) * dL_dreg; /* enters D below: dL_dweight - last_dL_dT obeys the same recurrence */ \
                         dL_dz = fmaf(conf * 2.0f * w * dm, dL_dreg, dL_dz);                                           \
                     } else {                                                                                          \
                         const float icd = fast_rcp(c_d);                                                              \
                         const float m_d = c1f * (1 - GS2D_NEAR_N * icd);                                              \
                         const float dmd_dd = (c1f * GS2D_NEAR_N) * (icd * icd);                                       \
                         dL_dweight = fmaf(m_d * m_d, final_A, fmaf(-2.0f * m_d, final_D, final_D2)) * dL_dreg;        \
-                        dL_dalpha += dL_dweight - last_dL_dT;                                                         \
-                        last_dL_dT = fmaf(dL_dweight, alpha, (1 - alpha) * last_dL_dT);                               \
                         const float dL_dmd = 2.0f * w * fmaf(m_d, final_A, -final_D) * dL_dreg;                       \
                         dL_dz = fmaf(dL_dmd, dmd_dd, dL_dz);                                                          \
                     }                                                                                                 \
-                    accum_depth_rec = fmaf(last_alpha, last_depth, (1.f - last_alpha) * accum_depth_rec);             \
-                    last_depth = c_d;                                                                                 \
-                    dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);                                    \
+                    D_ = fmaf(c_d, dL_ddepth, D_) + dL_dweight; /* backward.cu:380-385: the depth channel; :353-373: the regulariser */ \
                     if (ANY_DN) { /* backward.cu:392-397; the normal is not staged: rare path, read it from the record */ \
-                        const float4 nn = rec[(size_t)(wb.pn[J] & 0x0FFFFFFFu) * GS2D_REC_F4 + 3];                       \
-                        an0 = fmaf(last_alpha, ln0, (1.f - last_alpha) * an0); ln0 = nn.x;                            \
-                        dL_dalpha = fmaf(nn.x - an0, dn0, dL_dalpha);                                                 \
-                        an1 = fmaf(last_alpha, ln1, (1.f - last_alpha) * an1); ln1 = nn.y;                            \
-                        dL_dalpha = fmaf(nn.y - an1, dn1, dL_dalpha);                                                 \
-                        an2 = fmaf(last_alpha, ln2, (1.f - last_alpha) * an2); ln2 = nn.z;                            \
-                        dL_dalpha = fmaf(nn.z - an2, dn2, dL_dalpha);                                                 \
+                        const float4 nn = rec[(size_t)(wb.pn[J] & 0x0FFFFFFFu) * GS2D_REC_F4 + 3];                    \
+                        D_ = fmaf(nn.z, dn2, fmaf(nn.y, dn1, fmaf(nn.x, dn0, D_)));                                   \
                     }                                                                                                 \
+                    blend_S = fmaf(last_alpha, blend_Dprev, (1.f - last_alpha) * blend_S);                            \
+                    blend_Dprev = D_;                                                                                 \
+                    dL_dalpha += D_ - blend_S;                                                                        \
                     dL_dalpha *= T;                                                                                   \
                     last_alpha = alpha;                                                                               \
                     dL_dalpha = fmaf(-ioma, tf_bg, dL_dalpha);                                                        \
