@@ -589,7 +589,7 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
 // with v_permlane16/32_swap so that no trip needs the atomic (0.330 ms, +4 spills), and a per-row instead of
 // wave-uniform fallback (no change).
 #define GS2D_BWD_ACC_PRE(JJ)                                                                                            \
-    const int ai_ = (JJ) * NACC + (acc_comp < 0 ? 0 : acc_comp);                                                 \
+    const int ai_ = (int)__umul24((JJ), (uint32_t)NACC) + (acc_comp < 0 ? 0 : acc_comp); /* v_mul_lo_u32 is quarter rate */ \
     const float acc_old_ = wb.acc()[ai_];                                                                                 \
     /* do two rows hold the same splat in this trip?  Decided for all trips of the batch at once when the queues are    \
        built (clash_mask, one bit per trip): one scalar bit test here instead of four v_readlane + a scalar compare     \
@@ -723,12 +723,13 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     // The reference keeps, per blended channel x (r, g, b, depth, normal xyz), the back-to-front blend accum_x of the values
     // behind the current splat and adds (x - accum_x) * dL_dx to dL_dalpha (backward.cu:331-344, 380-397).  All channels are
     // blended with the same weights, so the SUM over the channels obeys one scalar recurrence:
-    //     D = sum_x x * dL_dx  (this splat),   S <- last_alpha * D_prev + (1 - last_alpha) * S,   dL_dalpha += D - S
+    //     D = sum_x x * dL_dx  (this splat),   dL_dalpha += D - S,   then  S <- alpha * D + (1 - alpha) * S
+    // (the reference defers the update of S to the next splat -- last_alpha, last_color; done at once it needs neither)
     // and the regulariser's  dL_dweight - last_dL_dT  (backward.cu:353-373: last_dL_dT <- dL_dweight alpha + (1 - alpha)
     // last_dL_dT, i.e. the same blend taken one splat later) is one more such channel with unit upstream gradient.
     // Two registers (S, D_prev) and nine operations per trip instead of nine registers (fifteen with normals) and two dozen
     // operations; the same sums in a different order (rounding-level deviation from the oracle's per-channel form)
-    float blend_S = 0.f, blend_Dprev = 0.f, last_alpha = 0.f;
+    float blend_S = 0.f;
 
     // nothing behind the deepest contributor of this quadrant can receive a gradient from it
     uint32_t max_last = last_contributor;
@@ -744,9 +745,8 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     max_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_last);
 
     // butterfly slot held by this lane -> offset in the gradient record, and the sign of that component.  Slots:
-    // 0-2 colour | 3-8 Tu,Tv (accumulated as +dk,+dl, the record wants -dk,-dl) | 9-11 Tw | 12-14 normal | 15 opacity
+    // 0-2 colour | 3-8 Tu,Tv (-dk, -dl) | 9-11 Tw | 12-14 normal | 15 opacity
     const int slot = reduce16_row_index(lane);
-    const uint32_t slot_sign = (slot >= 3 && slot <= 8) ? 0x80000000u : 0u;
     // LDS accumulator of this lane's slot; -1: normal component, added straight to the global record (not in DET: 13..15)
     const int acc_comp = slot < 12 ? slot : (slot == 15 ? 12 : (DET ? slot + 1 : -1));
 #pragma unroll
@@ -897,30 +897,29 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                 const float alpha = fminf(0.99f, G2.w * G);                                                           \
                 am &= ballot64(!(p2 == 0.0f)) & ballot64(!(c_d < GS2D_NEAR_N)) & ballot64(!(rho < 0.0f)) & ballot64(!(alpha < 1.0f / 255.0f)); \
                 const bool active = __builtin_amdgcn_inverse_ballot_w64(am);                                          \
-                /* Part B (contributing lanes only): state recurrences; it leaves six "drivers" from which every      \
+                /* Part B (contributing lanes only): state recurrences; it leaves four "drivers" from which every      \
                    gradient component follows linearly -- all zero for the lanes that do not contribute. */           \
-                float d_w = 0.f, d_gG = 0.f, d_zr = 0.f, d_zl = 0.f, d_t = 0.f, d_op = 0.f;                           \
+                float d_w = 0.f, d_x = 0.f, d_z = 0.f, d_op = 0.f;                                                    \
                 if (active) {                                                                                         \
                     const float ioma = fast_rcp(1.f - alpha);                                                         \
                     T = T * ioma;                                                                                     \
                     const float w = alpha * T;                                                                        \
-                    float dL_dalpha = 0.0f;                                                                           \
                     /* backward.cu:331-344: the colour part of D (see blend_S above) */                               \
                     float D_ = fmaf(cc.z, dpx2, fmaf(cc.y, dpx1, cc.x * dpx0));                                       \
                     float conf = 1.f;                                                                                 \
-                    if (USE_SA) { /* backward.cu:347-351 */                                                           \
-                        if (T < 0.5f) {                                                                               \
-                            const float dm = c_d - mm;                                                                \
-                            conf = fast_exp(-(dm * dm) * sa_k);                                                       \
-                        }                                                                                             \
-                        c_d = fmaf(c_d, conf, mm * (1 - conf));                                                       \
-                    }                                                                                                 \
                     float dL_dz = 0.0f, dL_dweight;                                                                   \
                     if (contributor == median_contributor - 1u) dL_dz = dL_dmedian_depth;                             \
-                    if (USE_SA) {                                                                                     \
-                        const float dm = c_d - mm;                                                                    \
+                    if (USE_SA) { /* backward.cu:347-351, 353-360 */                                                  \
+                        const float dm0 = c_d - mm;                                                                   \
+                        if (T < 0.5f) conf = fast_exp(-(dm0 * dm0) * sa_k);                                           \
+                        /* the re-weighted depth c_d conf + mm (1 - conf) = mm + conf (c_d - mm), and its distance from \
+                           the median, conf (c_d - mm), without forming (1 - conf) and without the cancellation of     \
+                           subtracting mm again (rounding-level deviation from the oracle's form) */                  \
+                        c_d = fmaf(conf, dm0, mm);                                                                    \
+                        const float dm = conf * dm0;                                                                  \
                         dL_dweight = (dm * dm) * dL_dreg; /* enters D below: dL_dweight - last_dL_dT obeys the same recurrence */ \
-                        dL_dz = fmaf(conf * 2.0f * w * dm, dL_dreg, dL_dz);                                           \
+                        const float cw2 = conf * w;                                                                   \
+                        dL_dz = fmaf((cw2 + cw2) * dm, dL_dreg, dL_dz);                                               \
                     } else {                                                                                          \
                         const float icd = fast_rcp(c_d);                                                              \
                         const float m_d = c1f * (1 - GS2D_NEAR_N * icd);                                              \
@@ -934,21 +933,17 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                         const float4 nn = rec[(size_t)(wb.pn[J] & 0x0FFFFFFFu) * GS2D_REC_F4 + 3];                    \
                         D_ = fmaf(nn.z, dn2, fmaf(nn.y, dn1, fmaf(nn.x, dn0, D_)));                                   \
                     }                                                                                                 \
-                    blend_S = fmaf(last_alpha, blend_Dprev, (1.f - last_alpha) * blend_S);                            \
-                    blend_Dprev = D_;                                                                                 \
-                    dL_dalpha += D_ - blend_S;                                                                        \
-                    dL_dalpha *= T;                                                                                   \
-                    last_alpha = alpha;                                                                               \
-                    dL_dalpha = fmaf(-ioma, tf_bg, dL_dalpha);                                                        \
-                    const float dL_dG = G2.w * dL_dalpha;                                                             \
-                    dL_dz = fmaf(conf * w, dL_ddepth, dL_dz);                                                         \
+                    const float DmS = D_ - blend_S;                                                                   \
+                    const float dL_dalpha = fmaf(-ioma, tf_bg, DmS * T);                                              \
+                    blend_S = fmaf(alpha, DmS, blend_S); /* S <- alpha D + (1 - alpha) S: what the next splat in front sees */ \
                     d_w = w;                                                                                          \
                     d_op = G * dL_dalpha;                                                                             \
-                    d_gG = ray ? dL_dG * -G : 0.f;                         /* backward.cu:419-449 */                  \
-                    d_zr = ray ? dL_dz : 0.f;                                                                         \
-                    d_zl = ray ? 0.f : dL_dz;                              /* backward.cu:450-457 */                  \
-                    d_t = ray ? 0.f : dL_dG * (-G * GS2D_FILTER_INV_SQ);                                              \
+                    d_x = (G2.w * dL_dalpha) * -G;                                                                    \
+                    d_z = fmaf(conf * w, dL_ddepth, dL_dz);                                                           \
                 }                                                                                                     \
+                /* ray-plane intersection / low-pass fall-back (backward.cu:419-449 / 450-457) */                     \
+                const float d_gG = ray ? d_x : 0.f, d_t = ray ? 0.f : d_x * GS2D_FILTER_INV_SQ;                       \
+                const float d_zr = ray ? d_z : 0.f, d_zl = ray ? 0.f : d_z;                                           \
                 if (GS2D_BWD_SKIP2(am != 0ull)) {                                                                      \
                     float g[16];                                                                                      \
                     g[0] = d_w * dpx0; g[1] = d_w * dpx1; g[2] = d_w * dpx2;                                          \
@@ -956,13 +951,15 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                     const float dL_ds1 = fmaf(d_gG, s1, d_zr * G2.y);                                                 \
                     const float dsx = dL_ds0 * ip, dsy = dL_ds1 * ip;                                                 \
                     const float dp2 = -fmaf(dsx, s0, dsy * s1);                                                       \
-                    const float dk0 = fmaf(l1, dp2, -(l2 * dsy)), dk1 = fmaf(l2, dsx, -(l0 * dp2)), dk2 = fmaf(l0, dsy, -(l1 * dsx)); \
-                    const float dl0 = fmaf(dsy, k2, -(dp2 * k1)), dl1 = fmaf(dp2, k0, -(dsx * k2)), dl2 = fmaf(dsx, k1, -(dsy * k0)); \
-                    g[3] = dk0; g[4] = dk1; g[5] = dk2; /* the record holds -dk, -dl: negated after the reduction (exact) */ \
-                    g[6] = dl0; g[7] = dl1; g[8] = dl2;                                                               \
-                    g[9] = fmaf(pxf, dk0, fmaf(pyf, dl0, d_zr * s0));                                                 \
-                    g[10] = fmaf(pxf, dk1, fmaf(pyf, dl1, d_zr * s1));                                                \
-                    g[11] = fmaf(pxf, dk2, fmaf(pyf, dl2, d_zr)) + d_zl;                                              \
+                    /* the record holds -dk, -dl: formed directly (operands of the cross products swapped; the sign of  \
+                       the Tw terms rides on the FMAs' source modifiers) -- exact, and no sign flip after the reduction */ \
+                    const float nk0 = fmaf(l2, dsy, -(l1 * dp2)), nk1 = fmaf(l0, dp2, -(l2 * dsx)), nk2 = fmaf(l1, dsx, -(l0 * dsy)); \
+                    const float nl0 = fmaf(dp2, k1, -(dsy * k2)), nl1 = fmaf(dsx, k2, -(dp2 * k0)), nl2 = fmaf(dsy, k0, -(dsx * k1)); \
+                    g[3] = nk0; g[4] = nk1; g[5] = nk2;                                                               \
+                    g[6] = nl0; g[7] = nl1; g[8] = nl2;                                                               \
+                    g[9] = fmaf(-pxf, nk0, fmaf(-pyf, nl0, d_zr * s0));                                               \
+                    g[10] = fmaf(-pxf, nk1, fmaf(-pyf, nl1, d_zr * s1));                                              \
+                    g[11] = fmaf(-pxf, nk2, fmaf(-pyf, nl2, d_zr)) + d_zl;                                            \
                     g[15] = d_op;                                                                                     \
                     /* each row reduces ITS splat into the splat's LDS accumulators */                                \
                     float tot;                                                                                        \
@@ -974,7 +971,6 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                         g[12] = 0.f; g[13] = 0.f; g[14] = 0.f;                                                        \
                         tot = reduce16_row_z(g, lane);                                                                \
                     }                                                                                                 \
-                    tot = __uint_as_float(__float_as_uint(tot) ^ slot_sign);                                          \
                     /* LDS float atomics run at a few lanes per clock: rows/components that sum to +-0 skip them */    \
                     if (DET) { /* one row at a time: lanes of different rows may hold the same (splat, component) */ \
                         _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++)                                              \
