@@ -118,9 +118,10 @@ __device__ __forceinline__ int pop_back(uint64_t& m)
 // only the loop counter (round 1 popped 64-bit bit-queues with ~65 scalar instructions per trip).
 struct FwdBatch {
     float4 qf[GS2D_REC_F4 * 64];  // staged records, SoA by quarter (q(k)[slot])
+    float4 dead;                  // = q(4)[64], the last quarter of the end marker's "record": its fourth word (list position + 1) is 0
     uint8_t ql[16][64];           // per-group queues: slot numbers in depth order, 64 = end.  The trip loop indexes records with
                                   // the marker unmasked: an exhausted group reads the next quarter's slot 0 (the last quarter:
-                                  // the first queue bytes) -- inside this struct, never used (the group is not live)
+                                  // `dead`) -- inside this struct, never used: contributor number 0 says "not live"
     __device__ __forceinline__ float4* q(int k) { return qf + k * 64; }
     uint32_t tail[4];           // the pipeline reads up to two entries past a full queue (values unused)
     uint16_t tm[64];            // group bits of the staged splats
@@ -263,6 +264,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     // the bytes behind the queues (the pipeline reads up to two entries past a full queue): wave-private, written once (the
     // LDS was the depth sort's until the barrier above)
     if (lane < 4) wb.tail[lane] = 0x40404040u;
+    if (lane == 4) wb.dead = make_float4(0.f, 0.f, 0.f, 0.f);
 
     float T = 1.0f, C0_ = 0.f, C1_ = 0.f, C2_ = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
     float Dp = 0.f, M1 = 0.f, M2 = 0.f, D2 = 0.f, distortion = 0.f, median_depth = 0.f;
@@ -314,7 +316,7 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
             const bool take = tm != 0u && slot < 64;
             if (take) {
                 wb.sid[slot] = id;
-                wb.spos[slot] = cbase - range.x + lane;  // the list position rides in the record's free word
+                wb.spos[slot] = cbase - range.x + lane + 1u;  // list position + 1 (the contributor number; 0: end marker) rides in the record's free word
                 wb.tm[slot] = (uint16_t)tm;
             }
             if (fill + c > 64) { carry_tm = take ? 0u : tm; carry_id = id; carry_base = cbase; carry = true; fill = 64; break; }
@@ -367,10 +369,12 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
 #define GS2D_FWD_STEP(C0, C1, C2, C3, C4, N0_, N1_, N2_, N3_, N4_, JN, JNN)                                          \
         {                                                                                                            \
             GS2D_PROF_TRIP();                                                                                        \
-            const bool live_ = JNN < 64u; /* JNN still holds THIS trip's queue entry; 64: this group's queue is exhausted */ \
+            const uint32_t contributor = __float_as_uint(C4.w); /* list position + 1; 0: this group's queue is exhausted (end marker) */ \
+            const bool live_ = contributor != 0u;                                                                    \
             N0_ = wb.q(0)[JN]; N1_ = wb.q(1)[JN]; N2_ = wb.q(2)[JN]; N3_ = wb.q(3)[JN];                              \
             N4_ = wb.q(4)[JN];                                                                                       \
             JNN = qrow[t + 2];                                                                                       \
+            asm volatile("" : "+v"(JNN)); /* a full 32-bit value from here on: ds_read_u8 zero-extends, no v_and 0xff later */ \
             float alpha, depth;                                                                                      \
             uint64_t ok_m;                                                                                           \
             fwd_eval(C0, C1, C2, pxf, pyf, alpha, depth, ok_m);                                                      \
@@ -379,11 +383,16 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
             const uint64_t stop_m = pass_m & ballot64(test_T < 0.0001f);                                             \
             done_m |= stop_m;                                                                                        \
             if (__builtin_amdgcn_inverse_ballot_w64(pass_m & ~stop_m)) {                                             \
-                const uint32_t contributor = __float_as_uint(C4.w) + 1u; /* list position + 1 */                    \
                 const float w = alpha * T;                                                                           \
-                if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }                            \
+                const uint64_t front_m = ballot64(T > 0.5f);                                                         \
+                if (__builtin_amdgcn_inverse_ballot_w64(front_m)) { median_depth = depth; median_contributor = contributor; } \
                 if (USE_SA) { /* forward.cu:405-416 */                                                               \
-                    if (Dp > 0) {                                                                                    \
+                    /* While T > 0.5 the median IS this depth: e = 0, conf = 1, the depth stays as it is (bit-exact), so  \
+                       those lanes skip the block.  The block itself keeps the oracle's operation order to the bit: the    \
+                       running variance is a difference of nearly equal sums -- rounding noise where the blended depths   \
+                       agree -- and conf depends on that noise at first order, so an algebraically equal form (one         \
+                       reciprocal instead of two was tried) moves mid-magnitude gradients by 1e-3 */                      \
+                    if (__builtin_amdgcn_inverse_ballot_w64(ballot64(Dp > 0) & ~front_m)) {                         \
                         const float exp_depth = median_depth;                                                        \
                         float exp_std = fmaf(fmaf(-2.0f * Dp, exp_depth, D2), fast_rcp(1 - T), exp_depth * exp_depth); \
                         exp_std = fmaxf(exp_std, 1e-7f);                                                             \
