@@ -3,8 +3,8 @@
 LDS / VMEM / waitcnt / nop per loop TRIP (one unrolled step of the software-pipelined trip loop), per staged CHUNK
 (staging loop body) and per FLUSH pass (backward only), for the shipped source.  Output kept as profiles/isa_mix_rNN.txt.
 
-Regions are located by anchors in the linear ISA: a trip step is the code between two consecutive queue reads
-(`ds_read_u8`) more than 40 instructions apart; the staging chunk is the loop body around the cull-bit byte load
+Regions are located by anchors in the linear ISA: a backward trip step is the code between two consecutive LDS
+accumulates, the forward's trip loop (two unrolled trips) the smallest loop around its last three `v_exp_f32`; the staging chunk is the loop body around the cull-bit byte load
 (`global_load_ubyte`); a flush pass is the loop body containing the gradient-record atomics (`global_atomic_add_f32`
 after the last trip step).  usage: isa_mix.py [path/to/gs2d_blend.hip]"""
 import collections
@@ -101,8 +101,15 @@ def main():
             da = [i for i, o in enumerate(names) if o == "ds_add_f32"]
             print(fmt("trip step (between LDS accumulates)", names[da[-2]:da[-1]]))
         else:
-            print(fmt("trip step A", names[rA:rB]))
-            print(fmt("trip step B", names[rB:(back + 1 if back else rB)]))
+            # the forward's two unrolled steps share their queue reads' positions with the record reads, so the loop as a whole
+            # is the unit: the smallest loop that contains the last three v_exp_f32 (two alpha exponentials + a confidence one)
+            ex = [i for i, o in enumerate(names) if o.startswith("v_exp_f32")]
+            body = None
+            for i, (op, arg) in enumerate(ops):
+                if op.startswith(("s_cbranch", "s_branch")) and arg in labels and labels[arg] < ex[-3] and ex[-1] < i:
+                    if body is None or i - labels[arg] < body[1] - body[0]:
+                        body = (labels[arg], i)
+            print(fmt("trip loop body = TWO trips", names[body[0]:body[1] + 1]))
         hb = [i for i, o in enumerate(names) if o == "global_load_ubyte" and i < rA]
         stage = loop_body_around(ops, labels, hb[-1]) if hb else None
         if stage:

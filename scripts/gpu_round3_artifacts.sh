@@ -1,5 +1,5 @@
 # Produces the measured artifacts of a round under gpurun_out/<tag>/ (copied into profiles/ by hand afterwards).
-# usage on the GPU box: bash scripts/gpu_round3_artifacts.sh <tag> <part>   (part 1: headline bench + rocprof + PMC; part 2: other workloads)
+# usage on the GPU box: bash scripts/gpu_round3_artifacts.sh <tag> <part>   (part 1: headline bench + rocprof + PMC; part 2: other workloads; part 3: headline bench again -- it quotes the PMC files part 1 produced, once they are in profiles/ -- and the two-rank rehearsal)
 set -e
 cd $GRAFT_REPO_ROOT
 TAG=${1:-r03_final}
@@ -21,7 +21,7 @@ if [ "$PART" = "1" ]; then
   python3 scripts/summarize_profile.py $OUT > $OUT/summary.txt 2>&1 || true
   python3 scripts/make_pmc_json.py $OUT > $OUT/make_pmc.log 2>&1 || true
   head -30 $OUT/summary.txt
-else
+elif [ "$PART" = "2" ]; then
   for w in b200k replica scannetpp scannetpp_ref tracking mapping; do
     timeout -k 10 300 python bench.py --workload $w --steps 30 --warmup 5 --no-cpu-baseline --no-extra-legs --json-out $OUT/bench_$w.json > $OUT/bench_$w.log 2>&1 || true
     echo "$w: $(python3 -c "import json;d=json.load(open('$OUT/bench_$w.json'));print(d['value'],d['unit'],d['ms_per_step'])" 2>/dev/null)"
