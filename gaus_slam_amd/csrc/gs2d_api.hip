@@ -280,6 +280,13 @@ int fwd_validate(const FwdShared& c)
 // with `pause` for at most ~100 us; if the stream is backed up behind earlier work (or several ranks share the host's cores)
 // it hands its time slice back between looks instead of burning a core per rank.  Falls back to a real synchronise after
 // ~2 s (surfacing any GPU error).
+// The wait is typically as long as the previous backward (the host runs one step ahead: 0.25 ms at the bench size), so the
+// calling thread spins through it; it starts yielding its core only after a millisecond.  (Yielding after 100 us, as until
+// round 3, put every steady-state wait into sched_yield: on a box with busy neighbours the thread can lose its core for a
+// whole time slice that way -- host steps of 0.6-0.9 ms were seen once in a few hundred, scripts/dev/window_jitter.py.)
+#ifndef GS2D_SPIN_BEFORE_YIELD_US
+#define GS2D_SPIN_BEFORE_YIELD_US 1000
+#endif
 bool wait_total(FwdFrame& f, hipStream_t s)
 {
     if (!f.store_pending) return true;
@@ -292,7 +299,7 @@ bool wait_total(FwdFrame& f, hipStream_t s)
         if ((++spins & (yielding ? 0x3Fu : 0x3FFu)) == 0) {
             const auto dt = std::chrono::steady_clock::now() - t0;
             if (dt > std::chrono::seconds(2)) return hipStreamSynchronize(s) == hipSuccess && *f.pinned != 0xFFFFFFFFu;
-            if (dt > std::chrono::microseconds(100)) yielding = true;
+            if (dt > std::chrono::microseconds(GS2D_SPIN_BEFORE_YIELD_US)) yielding = true;
         }
     }
     return true;

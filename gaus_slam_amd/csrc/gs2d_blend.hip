@@ -736,7 +736,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     // (the reference defers the update of S to the next splat -- last_alpha, last_color; done at once it needs neither)
     // and the regulariser's  dL_dweight - last_dL_dT  (backward.cu:353-373: last_dL_dT <- dL_dweight alpha + (1 - alpha)
     // last_dL_dT, i.e. the same blend taken one splat later) is one more such channel with unit upstream gradient.
-    // Two registers (S, D_prev) and nine operations per trip instead of nine registers (fifteen with normals) and two dozen
+    // One register (S) and six operations per trip instead of nine registers (fifteen with normals) and two dozen
     // operations; the same sums in a different order (rounding-level deviation from the oracle's per-channel form)
     float blend_S = 0.f;
 
