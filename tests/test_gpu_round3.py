@@ -180,6 +180,8 @@ def test_backward_parity_includes_knife_edge_pixels_and_mid_magnitude_entries(or
     oracle.set_threads(1)
     for k in ALL_GRADS:
         ref = go[k].reshape(gh[k].shape)
+        print(f"{k}: max-norm error {util.grad_err(gh[k], ref):.2e} (limit {GRAD_TOL:.0e}), mid-magnitude relative error "
+              f"{util.grad_err_mid(gh[k], ref):.2e} (limit {MID_TOL:.0e})")
         assert util.grad_err(gh[k], ref) <= GRAD_TOL, k
         assert util.grad_err_mid(gh[k], ref) <= MID_TOL, (k, util.grad_err_mid(gh[k], ref))
 
@@ -219,6 +221,8 @@ def test_full_size_default_mode_against_the_oracle(oracle):
     for k in ALL_GRADS:
         np.testing.assert_array_equal(gt[k].view(np.uint32), go[k].view(np.uint32), err_msg=k)
         ref = go[k].reshape(gh[k].shape)
+        print(f"{k}: max-norm error {util.grad_err(gh[k], ref):.2e} (limit {GRAD_TOL:.0e}), mid-magnitude relative error "
+              f"{util.grad_err_mid(gh[k], ref):.2e} (limit {MID_TOL:.0e})")
         assert util.grad_err(gh[k], ref) <= GRAD_TOL, k
         assert util.grad_err_mid(gh[k], ref) <= MID_TOL, (k, util.grad_err_mid(gh[k], ref))
 
