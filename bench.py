@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--keyframes-per-gpu", type=int, default=1, help="keyframes each rank renders per step (default 1 = the "
                     "headline metric); rendered one after the other unless --streams 2")
+    ap.add_argument("--loss-autograd", action="store_true", help="tracking / mapping workloads: the fused loss as an autograd node "
+                    "(loss.backward(): three loss kernels per iteration) instead of the one-call loss + gradients (two)")
     ap.add_argument("--no-batch", action="store_true", help="--keyframes-per-gpu > 1: render a rank's keyframes one operator call "
                     "after the other instead of one batched call (gs2d_forward_batch / gs2d_backward_batch)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams a rank spreads its keyframes over (ba_shard.KeyframeShardedBA)")
@@ -487,9 +489,13 @@ def slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world):
         def one_step():
             opt.zero_grad(set_to_none=True)
             pkg = tracking.render_tracking(settings, w2c, p["means3D"], p["opacities"], p["colors"], p["scales"], p["rotations"])
-            gl.tracking_loss(pkg["render_color"], pkg["allmap"], gt_color, gt_depth, 0.5, 1.0).backward(one)
+            if args.loss_autograd:
+                gl.tracking_loss(pkg["render_color"], pkg["allmap"], gt_color, gt_depth, 0.5, 1.0).backward(one)
+            else:  # loss value + gradients in one call, the rasterizer's backward seeded directly
+                _loss, g_c, g_a = gl.tracking_loss_and_grads(pkg["render_color"], pkg["allmap"], gt_color, gt_depth, 0.5, 1.0)
+                torch.autograd.backward([pkg["render_color"], pkg["allmap"]], [g_c, g_a])
             opt.step()
-        step_desc = "pose transform fused into the preprocess + render + fused tracking loss + pose-only backward + Adam on the pose"
+        step_desc = "pose transform fused into the preprocess + render + fused tracking loss (value + gradients in one call) + pose-only backward + Adam on the pose"
         metric = f"tracking iterations/sec @ {W}x{H}, {P // 1000}k Gaussians"
     else:
         sc = make_scene(P, W, H, seed=0, regime="mapping")
@@ -505,13 +511,16 @@ def slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world):
 
         def loss_fn(q, _kf):
             pk = rasterize(q)
-            return gl.mapping_loss(pk["render_color"], pk["allmap"], gt_color, gt_depth, 0.5, 1.0, 0.1)
+            if args.loss_autograd:
+                return gl.mapping_loss(pk["render_color"], pk["allmap"], gt_color, gt_depth, 0.5, 1.0, 0.1)
+            _loss, g_c, g_a = gl.mapping_loss_and_grads(pk["render_color"], pk["allmap"], gt_color, gt_depth, 0.5, 1.0, 0.1)
+            return (pk["render_color"], pk["allmap"]), (g_c, g_a)
         ba = ba_shard.KeyframeShardedBA(leaves, loss_fn, direct_grads=True)
 
         def one_step():
             ba.step([0])
             fopt.step(ba.bucket.flat, leaves)
-        step_desc = "render + fused mapping loss + backward (gradients written into the bucket) + fused Adam over the SoA"
+        step_desc = "render + fused mapping loss (value + gradients in one call) + backward (gradients written into the bucket) + fused Adam over the SoA"
         metric = f"mapping iterations/sec @ {W}x{H}, {P // 1000}k Gaussians"
     elapsed = timed(one_step, args.steps, args.warmup, world, dev)
     return {"metric": metric, "value": round(args.steps / elapsed, 3), "unit": "iterations/s", "n_gpus": 1, "steps": args.steps,

@@ -75,7 +75,7 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 // Pass 1: per-block partial sums, partial[b*5 + k] with k = 0: sum |c - gt| over the colour mask, 1: sum |d - gt| over
 // its mask, 2: sum dist over the colour mask, 3: #colour-mask pixels, 4: #depth-mask pixels  (doubles; no atomics: a few
 // hundred blocks hammering five addresses cost 50 us, the per-block partials are re-reduced by every block of pass 2).
-constexpr int LOSS_MAX_BLOCKS = 256;
+constexpr int LOSS_MAX_BLOCKS = 512;  // two workgroups per CU: the pass is latency-bound (13.8 us with 256, one wave per SIMD)
 
 __global__ void __launch_bounds__(256)
 loss_reduce_kernel(LossCfg L, int HWi, const float* __restrict__ color, const float* __restrict__ allmap,
@@ -102,7 +102,7 @@ loss_reduce_kernel(LossCfg L, int HWi, const float* __restrict__ color, const fl
     }
 }
 
-// Pass 2: every block first folds the (<= 256) per-block partials into the five totals, then writes the gradients of
+// Pass 2: every block first folds the (<= LOSS_MAX_BLOCKS) per-block partials into the five totals, then writes the gradients of
 // its pixels; block 0 also writes the loss.
 __global__ void __launch_bounds__(256)
 loss_grad_kernel(LossCfg L, int HWi, int nparts, const float* __restrict__ color, const float* __restrict__ allmap,
@@ -113,7 +113,11 @@ loss_grad_kernel(LossCfg L, int HWi, int nparts, const float* __restrict__ color
     __shared__ double red[4];
     const size_t HW = (size_t)HWi;
     double acc[5];
-    for (int i = 0; i < 5; i++) acc[i] = block_sum((int)threadIdx.x < nparts ? partial[threadIdx.x * 5 + i] : 0.0, red);
+    for (int i = 0; i < 5; i++) {
+        double v = 0.0;
+        for (int j = threadIdx.x; j < nparts; j += 256) v += partial[j * 5 + i];
+        acc[i] = block_sum(v, red);
+    }
     const double nc = acc[3], nd = acc[4];
     float gc_scale, gd_scale, gdist_scale;
     if (L.mode == 0) { gc_scale = L.w_color; gd_scale = L.w_depth; gdist_scale = 0.f; }
@@ -172,7 +176,7 @@ extern "C" int gs2d_slam_loss(int mode, int width, int height, const float* colo
     L.eps = eps; L.depth_near = depth_near; L.depth_far = depth_far;
     const int HW = width * height;
     const int blocks = (HW + 255) / 256;
-    const int rgrid = blocks < LOSS_MAX_BLOCKS ? blocks : LOSS_MAX_BLOCKS;  // one partial per reduce block, <= 256
+    const int rgrid = blocks < LOSS_MAX_BLOCKS ? blocks : LOSS_MAX_BLOCKS;  // one partial per reduce block
     const int ggrid = blocks < 2048 ? blocks : 2048;
     static_assert(LOSS_MAX_BLOCKS * 5 <= GS2D_LOSS_WS_DOUBLES, "workspace too small");
     // loss_out != NULL: run the reduction (pass 1).  dL_d* != NULL: write gradients (pass 2, scaled by *upstream if

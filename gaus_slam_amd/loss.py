@@ -12,6 +12,8 @@ import torch
 from . import _lib
 from .rasterizer import _on_device, _stream_ptr
 
+_WS_DOUBLES = 2560  # GS2D_LOSS_WS_DOUBLES (include/gs2d_rasterizer.h)
+
 
 def _call(cfg, W, H, color_, allmap_, gtc, gtd, ws, out, g_color, g_allmap, upstream, dev):
     p = lambda t: None if t is None else t.data_ptr()
@@ -40,7 +42,7 @@ class _SlamLoss(torch.autograd.Function):
         color_, allmap_ = color.detach().float().contiguous(), allmap.detach().float().contiguous()
         gtc = gt_color.detach().float().contiguous().reshape(H, W, 3)
         gtd = gt_depth.detach().float().contiguous().reshape(H, W)
-        ws = torch.empty(1280, dtype=torch.float64, device=dev)  # GS2D_LOSS_WS_DOUBLES
+        ws = torch.empty(_WS_DOUBLES, dtype=torch.float64, device=dev)
         out = torch.empty(8, dtype=torch.float32, device=dev)
         _call(cfg, W, H, color_, allmap_, gtc, gtd, ws, out, None, None, None, dev)
         ctx.save_for_backward(color_, allmap_, gtc, gtd, ws)
@@ -57,6 +59,42 @@ class _SlamLoss(torch.autograd.Function):
         up = grad_loss.detach().to(dtype=torch.float32).contiguous()
         _call(ctx.cfg, W, H, color_, allmap_, gtc, gtd, ws, None, g_color, g_allmap, up, dev)
         return g_color, g_allmap, None, None, None
+
+
+def _loss_and_grads(color, allmap, gt_color, gt_depth, cfg):
+    if not color.is_cuda:
+        raise RuntimeError("color must be a CUDA tensor")
+    dev = color.device
+    H, W = color.shape[1], color.shape[2]
+    color_, allmap_ = color.detach().float().contiguous(), allmap.detach().float().contiguous()
+    gtc = gt_color.detach().float().contiguous().reshape(H, W, 3)
+    gtd = gt_depth.detach().float().contiguous().reshape(H, W)
+    ws = torch.empty(_WS_DOUBLES, dtype=torch.float64, device=dev)
+    out = torch.empty(8, dtype=torch.float32, device=dev)
+    g_color, g_allmap = torch.empty_like(color_), torch.empty_like(allmap_)
+    _call(cfg, W, H, color_, allmap_, gtc, gtd, ws, out, g_color, g_allmap, None, dev)
+    return out[0], g_color, g_allmap
+
+
+def tracking_loss_and_grads(color, allmap, gt_color, gt_depth, w_color, w_depth, silmask_th=0.9, use_weight_norm=True, eps=1e-6,
+                            depth_near=1e-2, depth_far=1e2):
+    """tracking_loss and its gradients w.r.t. the rasterizer outputs in ONE call -- two kernels (reduce; gradients + loss)
+    instead of the three of the autograd node (reduce, loss, and the gradient pass again in backward), and no second autograd
+    node.  For iteration loops that seed the rasterizer's backward themselves:
+        loss, g_color, g_allmap = tracking_loss_and_grads(pkg["render_color"], pkg["allmap"], ...)
+        torch.autograd.backward([pkg["render_color"], pkg["allmap"]], [g_color, g_allmap])
+    Returns (loss, dL_dcolor [3, H, W], dL_dallmap [7, H, W]); the values equal tracking_loss(...) and its .backward()."""
+    return _loss_and_grads(color, allmap, gt_color, gt_depth, dict(
+        mode=0, w_color=w_color, w_depth=w_depth, silmask_th=silmask_th, use_weight_norm=use_weight_norm, eps=eps,
+        depth_near=depth_near, depth_far=depth_far))
+
+
+def mapping_loss_and_grads(color, allmap, gt_color, gt_depth, w_color, w_depth, w_dist, use_edge_growth=False, edge_thres=0.4,
+                           use_weight_norm=True, eps=1e-6, depth_near=1e-2, depth_far=1e2):
+    """mapping_loss and its gradients in one call (see tracking_loss_and_grads)."""
+    return _loss_and_grads(color, allmap, gt_color, gt_depth, dict(
+        mode=1, w_color=w_color, w_depth=w_depth, w_dist=w_dist, use_edge_growth=use_edge_growth, edge_thres=edge_thres,
+        use_weight_norm=use_weight_norm, eps=eps, depth_near=depth_near, depth_far=depth_far))
 
 
 def tracking_loss(color, allmap, gt_color, gt_depth, w_color, w_depth, silmask_th=0.9, use_weight_norm=True, eps=1e-6,

@@ -269,7 +269,7 @@ int sknn_dist2(int N, const float* points, float* out,
  * loss_out = NULL (same inputs, same workspace) for the gradients, scaled by the device scalar *upstream.
  * Default-configuration losses only (no normal loss, no outlier rejection, no exposure).
  */
-#define GS2D_LOSS_WS_DOUBLES 1280
+#define GS2D_LOSS_WS_DOUBLES 2560
 int gs2d_slam_loss(int mode, int width, int height, const float* color, const float* allmap, const float* gt_color_hwc,
                    const float* gt_depth, float w_color, float w_depth, float w_dist, float silmask_th, float edge_thres,
                    int use_edge_growth, int use_weight_norm, float eps, float depth_near, float depth_far,

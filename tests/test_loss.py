@@ -65,3 +65,29 @@ def test_fused_loss_matches_reference_formulation(mode, edge, weight_norm):
         assert ok.float().mean() > 0.99
         assert util.grad_err(mine[ok].numpy(), ref_g[ok].numpy()) < 1e-5
     assert torch.isfinite(cg.grad).all() and torch.isfinite(ag.grad).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("size", [(200, 136), (640, 480)])
+def test_one_call_loss_and_grads_equal_the_autograd_node(mode, size):
+    """tracking_/mapping_loss_and_grads (value + gradients in one library call: two kernels) against the autograd node (three):
+    same value, same gradients, bit for bit -- both run the same two passes over the same partial sums.  640x480 has more
+    pixels than reduce workgroups x 256, so the strided pixel loop and the 512-partial fold are exercised."""
+    from gaus_slam_amd import loss as gl
+    W, H = size
+    color, allmap, gt_color, gt_depth = _inputs(W, H, seed=7 + mode)
+    dev = torch.device("cuda")
+    cg = color.to(dev).requires_grad_(True)
+    ag = allmap.to(dev).requires_grad_(True)
+    gc, gd = gt_color.to(dev), gt_depth.to(dev)
+    if mode == 0:
+        out = gl.tracking_loss(cg, ag, gc, gd, 0.5, 1.0)
+        loss, g_c, g_a = gl.tracking_loss_and_grads(cg, ag, gc, gd, 0.5, 1.0)
+    else:
+        out = gl.mapping_loss(cg, ag, gc, gd, 0.5, 1.0, 0.1)
+        loss, g_c, g_a = gl.mapping_loss_and_grads(cg, ag, gc, gd, 0.5, 1.0, 0.1)
+    out.backward()
+    assert torch.equal(loss, out.detach())
+    assert torch.equal(g_c, cg.grad) and torch.equal(g_a, ag.grad)
+    assert not g_c.requires_grad and not g_a.requires_grad
