@@ -309,7 +309,7 @@ int fwd_phase_a(const FwdShared& c, FwdFrame& f, int slot)
 {
     const int debug = c.debug;
     hipStream_t s = c.s;
-    if ((f.pose_Rt == nullptr) != (f.pose_quat == nullptr)) return fail_msg("pose_Rt and pose_quat must be given together");
+    if (f.pose_Rt == nullptr && f.pose_quat != nullptr) return fail_msg("pose_quat without pose_Rt");
     if (f.pose_Rt != nullptr && c.transMat_precomp != nullptr) return fail_msg("a pose cannot be combined with transMat_precomp");
     if (!f.geometry_alloc || !f.binning_alloc || !f.image_alloc) return fail_msg("allocator callbacks are required");
     f.GL = geom_layout(c.P);
@@ -620,7 +620,7 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     c.background = background; c.means3D = means3D; c.shs = shs; c.colors_precomp = colors_precomp; c.opacities = opacities;
     c.scales = scales; c.rotations = rotations; c.transMat_precomp = transMat_precomp; c.scale_modifier = scale_modifier;
     c.s = (hipStream_t)stream;
-    if ((pose_Rt == nullptr) != (pose_quat == nullptr)) return fail_msg("pose_Rt and pose_quat must be given together");
+    if (pose_Rt == nullptr && pose_quat != nullptr) return fail_msg("pose_quat without pose_Rt");
     if (pose_Rt != nullptr && transMat_precomp != nullptr) return fail_msg("a pose cannot be combined with transMat_precomp");
     if (fwd_validate(c) < 0) return -1;
     if (P == 0) return 0;  // rasterize_points.cu:100-101: zero images, rendered = 0 (outputs pre-zeroed by the caller)
@@ -710,7 +710,7 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         return fail_msg("stages must be a combination of GS2D_BWD_BLEND (1) and GS2D_BWD_PREPROCESS (2), optionally with GS2D_BWD_POSE_4X4 (4)");
     if ((stages & GS2D_BWD_POSE_4X4) != 0 && (stages & 3) != 3)
         return fail_msg("GS2D_BWD_POSE_4X4 needs both stages in one call");
-    if ((pose_Rt == nullptr) != (pose_quat == nullptr)) return fail_msg("pose_Rt and pose_quat must be given together");
+    if (pose_Rt == nullptr && pose_quat != nullptr) return fail_msg("pose_quat without pose_Rt");
     if (pose_Rt != nullptr && dL_dpose == nullptr) return fail_msg("dL_dpose is required with a pose");
     if ((stages & 2) != 0) {   // pose-only call: all six per-Gaussian outputs NULL (needs a pose and no SH gradient), otherwise none of them
         const int nulls = !dL_dmean2D + !dL_dopacity + !dL_dcolor + !dL_dmean3D + !dL_dscale + !dL_drot;

@@ -151,9 +151,8 @@ __device__ void sh_to_rgb(int idx, int deg, int M, float posx, float posy, float
 // (four candidates from the diagonal, the best-conditioned one wins, first maximum on ties), in the same float32
 // operation order as gaus_slam_amd/tracking.py::matrix_to_quaternion.  One thread: it exists so that a tracking
 // iteration needs neither a host sync (argmax -> index) nor ~20 tiny PyTorch launches for four numbers.
-__global__ void pose_quat_kernel(const float* __restrict__ Rt, float* __restrict__ q_out)
+__device__ __forceinline__ void pose_quat_from_Rt(const float* __restrict__ Rt, float q_out[4])
 {
-    if (threadIdx.x != 0) return;
     const float m00 = Rt[0], m01 = Rt[1], m02 = Rt[2], m10 = Rt[4], m11 = Rt[5], m12 = Rt[6], m20 = Rt[8], m21 = Rt[9], m22 = Rt[10];
     const float qa[4] = {sqrtf(fmaxf(((1.0f + m00) + m11) + m22, 0.f)), sqrtf(fmaxf(((1.0f + m00) - m11) - m22, 0.f)),
                          sqrtf(fmaxf(((1.0f - m00) + m11) - m22, 0.f)), sqrtf(fmaxf(((1.0f - m00) - m11) + m22, 0.f))};
@@ -169,6 +168,21 @@ __global__ void pose_quat_kernel(const float* __restrict__ Rt, float* __restrict
     for (int i = 0; i < 4; i++) q[i] = cand[best][i] / den;
     const bool neg = q[0] < 0.f;
     for (int i = 0; i < 4; i++) q_out[i] = neg ? -q[i] : q[i];
+}
+__global__ void pose_quat_kernel(const float* __restrict__ Rt, float* __restrict__ q_out)
+{
+    if (threadIdx.x != 0) return;
+    float q[4];
+    pose_quat_from_Rt(Rt, q);
+    for (int i = 0; i < 4; i++) q_out[i] = q[i];
+}
+// q_cam of a posed call: the caller's (gs2d_pose_quat's output, or its own), or -- pose_q == NULL -- derived here from the
+// rotation block, the same code gs2d_pose_quat runs (every thread for itself: fifty operations, no kernel and no dependent
+// dispatch in front of the preprocess of every tracking iteration)
+__device__ __forceinline__ void load_pose_quat(const float* __restrict__ pose_Rt, const float* __restrict__ pose_q, float q[4])
+{
+    if (pose_q != nullptr) { q[0] = pose_q[0]; q[1] = pose_q[1]; q[2] = pose_q[2]; q[3] = pose_q[3]; }
+    else pose_quat_from_Rt(pose_Rt, q);
 }
 
 __device__ __forceinline__ void
@@ -203,7 +217,7 @@ preprocess_fwd_body(int P, int D, int M, const float* __restrict__ means3D, cons
         float T[9], normal[3];
         if (transMat_precomp == nullptr) {
             float4 q = reinterpret_cast<const float4*>(rotations)[idx];
-            if (pose_q != nullptr) { float sgn; q = pose_quat(pose_q, q, sgn); }
+            if (pose_Rt != nullptr) { float sgn, qc[4]; load_pose_quat(pose_Rt, pose_q, qc); q = pose_quat(qc, q, sgn); }
             const float2 sc = reinterpret_cast<const float2*>(scales)[idx];
             float w, x, y, z;
             const Mat3 R = quat_to_R(q, w, x, y, z);
@@ -467,6 +481,7 @@ preprocess_bwd_one(int idx, int P, int D, int M, const float* __restrict__ means
     float Pm[4][3];
     Mat3 R;
     float sx = 0.f, sy = 0.f, w = 0.f, x = 0.f, y = 0.f, z = 0.f, qsign = 1.f;
+    float qcam[4] = {1.f, 0.f, 0.f, 0.f};
     // rec == nullptr (launch_preprocess_bwd): Tw.z, the one word of the record the usual path needs, is recomputed below bit
     // for bit, so the 80-byte-strided record reads (a whole line per Gaussian for four useful bytes) are not issued
     float4 q2 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -477,7 +492,7 @@ preprocess_bwd_one(int idx, int P, int D, int M, const float* __restrict__ means
         T[0] = q0.x; T[1] = q0.y; T[2] = q0.z; T[3] = q1.x; T[4] = q1.y; T[5] = q1.z; T[6] = q2.x; T[7] = q2.y; T[8] = q2.z;
     } else {
         float4 q = reinterpret_cast<const float4*>(rotations)[idx];
-        if (pose_q != nullptr) q = pose_quat(pose_q, q, qsign);
+        if (pose_Rt != nullptr) { load_pose_quat(pose_Rt, pose_q, qcam); q = pose_quat(qcam, q, qsign); }
         const float2 sc = reinterpret_cast<const float2*>(scales)[idx];
         sx = sc.x; sy = sc.y;  // backward.cu:504: scale_modifier is ignored here
         R = quat_to_R(q, w, x, y, z);
@@ -536,8 +551,8 @@ preprocess_bwd_one(int idx, int P, int D, int M, const float* __restrict__ means
         dq.y = 2.f * (-2.f * x * (v[1][1] + v[2][2]) + y * (v[1][0] + v[0][1]) + z * (v[2][0] + v[0][2]) + w * (v[2][1] - v[1][2]));
         dq.z = 2.f * (x * (v[1][0] + v[0][1]) - 2.f * y * (v[0][0] + v[2][2]) + z * (v[2][1] + v[1][2]) + w * (v[0][2] - v[2][0]));
         dq.w = 2.f * (x * (v[2][0] + v[0][2]) + y * (v[2][1] + v[1][2]) - 2.f * z * (v[0][0] + v[1][1]) + w * (v[1][0] - v[0][1]));
-        if (pose_q != nullptr) {  // dL/dq = sign * L(q_cam)^T dL/dq'
-            const float aw = pose_q[0], ax = pose_q[1], ay = pose_q[2], az = pose_q[3];
+        if (pose_Rt != nullptr) {  // dL/dq = sign * L(q_cam)^T dL/dq'
+            const float aw = qcam[0], ax = qcam[1], ay = qcam[2], az = qcam[3];
             const float4 t = dq;
             dq.x = qsign * (((aw * t.x + ax * t.y) + ay * t.z) + az * t.w);
             dq.y = qsign * (((-ax * t.x + aw * t.y) + az * t.z) - ay * t.w);

@@ -174,8 +174,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             raise RuntimeError("pose_only_out needs a pose and colors_precomp")
         if P != 0:
             keep = [_f32c(t) for t in (background, means3D, colors, scales, rotations, viewmatrix, projmatrix, campos,
-                                       dL_dout_color, dL_dout_others, pose_Rt, pose_quat)]
-            bg_, m3_, col_, sc_, rot_, vm_, pm_, cp_, dc_, do_, prt_, pq_ = keep
+                                       dL_dout_color, dL_dout_others, pose_Rt)]
+            bg_, m3_, col_, sc_, rot_, vm_, pm_, cp_, dc_, do_, prt_ = keep
+            pq_ = _f32c(pose_quat) if pose_quat is not None else None  # None: the kernels derive q_cam from pose_Rt
             with _on_device(dev):
                 # stages 1|2|4 (GS2D_BWD_POSE_4X4): all sixteen floats of pose_only_out are written
                 rc = L.gs2d_backward_staged(

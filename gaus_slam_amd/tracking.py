@@ -50,7 +50,9 @@ class _RasterizeTracking(torch.autograd.Function):
     def forward(ctx, w2c, means3D, colors_precomp, opacities, scales, rotations, raster_settings):
         rs = raster_settings
         pose_Rt = w2c[:3, :4].detach().float().contiguous()
-        pose_q = pose_quaternion(pose_Rt)
+        # q_cam is derived from pose_Rt inside the preprocess kernels (pose_quat=None): the code of gs2d_pose_quat /
+        # pose_quaternion(), without its launch
+        pose_q = None
         e = torch.empty(0, dtype=torch.float32, device=means3D.device)
         num_rendered, color, allmap, radii, geom, binning, img = _r.rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, e, rs.viewmatrix,
@@ -58,7 +60,7 @@ class _RasterizeTracking(torch.autograd.Function):
             rs.use_sa, rs.prefiltered, rs.debug, pose_Rt=pose_Rt, pose_quat=pose_q)
         ctx.rs = rs
         ctx.num_rendered = num_rendered
-        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, radii, geom, binning, img, pose_Rt, pose_q)
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, radii, geom, binning, img, pose_Rt)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)  # no zero-filled [P] "gradient" of radii per call (rasterizer._RasterizeGaussians)
         ctx.image_shape = (color.shape, allmap.shape)
@@ -67,7 +69,8 @@ class _RasterizeTracking(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_allmap):
         rs = ctx.rs
-        colors_precomp, means3D, scales, rotations, radii, geom, binning, img, pose_Rt, pose_q = ctx.saved_tensors
+        colors_precomp, means3D, scales, rotations, radii, geom, binning, img, pose_Rt = ctx.saved_tensors
+        pose_q = None
         e = torch.empty(0, dtype=torch.float32, device=means3D.device)
         if grad_color is None:
             grad_color = torch.zeros(ctx.image_shape[0], dtype=torch.float32, device=means3D.device)

@@ -125,7 +125,9 @@ int gs2d_backward(
  * first), and the backward additionally returns the pose gradient
  *     dL_dpose[12] (row-major [dL/dR | dL/dt]),  dL/dR = sum_i g_i (x) x_i,  dL/dt = sum_i g_i,
  * with dL_dmean3D = R^T g_i and dL_drot mapped back to the untransformed quaternions.
- * pose_Rt: 12 floats row-major [R | t] (device); pose_quat: q_cam (w,x,y,z) (device).  Both NULL = plain call.
+ * pose_Rt: 12 floats row-major [R | t] (device); pose_quat: q_cam (w,x,y,z) (device).  Both NULL = plain call.  pose_quat alone
+ * may be NULL: the kernels then derive it from pose_Rt's rotation block themselves (gs2d_pose_quat's code, same bits; no
+ * extra launch in front of every tracking iteration); a caller with a quaternion of its own passes it.
  * Typical use: identity viewmatrix / projection of the intrinsics only, as the reference's tracking renderer does.
  * Pose-only backward: with a pose (and no SH), dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dscale and dL_drot may
  * ALL be NULL -- tracking detaches every Gaussian parameter (render/__init__.py:31-36), only dL_dpose is produced then.

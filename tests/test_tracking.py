@@ -162,3 +162,42 @@ def test_device_pose_quaternion_matches_torch_restatement():
         got = tracking.pose_quaternion(Rt).cpu()
         want = tracking.matrix_to_quaternion(w[:3, :3].float())
         assert torch.allclose(got, want, atol=1e-6, rtol=0), (got, want)
+
+
+@pytest.mark.gpu
+def test_pose_quaternion_derived_in_the_kernels_equals_the_passed_one():
+    """gs2d_forward_posed / gs2d_backward_posed with pose_quat = NULL derive q_cam from pose_Rt inside the preprocess kernels
+    (the path render_tracking takes: no gs2d_pose_quat launch per iteration).  Outputs and gradients are bit-identical to the
+    calls that are handed gs2d_pose_quat's result, for rotations whose largest quaternion component differs."""
+    from gaus_slam_amd import rasterizer, tracking
+    from gaus_slam_amd.scene_synth import random_w2c
+    W, H, P = 160, 120, 1500
+    dev = torch.device("cuda")
+    e = torch.empty(0, device=dev)
+    t = lambda a: a.to(dev).contiguous()
+    dc, da = util.make_upstream_grads(W, H, channels=(0, 1, 5, 6))
+    dc, da = (dc * W * H).to(dev), (da * W * H).to(dev)
+    for seed, max_rot in ((21, 25.0), (22, 120.0), (23, 175.0)):
+        sc, _ = _world_scene(P, W, H, seed=seed)
+        w2c = random_w2c(np.random.default_rng(seed), max_rot_deg=max_rot, max_trans=0.2)
+        cam = sc["cam"]
+        Rt = t(w2c[:3, :4])
+        qc = tracking.pose_quaternion(Rt)
+        args = (torch.zeros(3, device=dev), t(sc["means3D"]), t(sc["colors"]), t(sc["opacities"]), t(sc["scales"]),
+                t(sc["rotations"]), 1.0, e, t(cam.viewmatrix), t(cam.projmatrix), cam.tanfovx, cam.tanfovy, H, W, e, 0,
+                t(cam.campos), True, False, False)
+        outs = []
+        for q in (qc, None):
+            R, color, allmap, radii, geom, binning, img = rasterizer.rasterize_gaussians(*args, pose_Rt=Rt, pose_quat=q)
+            rasterizer.set_deterministic(True)  # no float atomics: the two backward calls can be compared bit for bit
+            try:
+                R, color, allmap, radii, geom, binning, img = rasterizer.rasterize_gaussians(*args, pose_Rt=Rt, pose_quat=q)
+                res = rasterizer.rasterize_gaussians_backward(
+                    args[0], args[1], radii, args[2], args[4], args[5], 1.0, e, args[8], args[9], args[10], args[11], dc, da, e, 0,
+                    args[16], geom, R, binning, img, True, False, pose_Rt=Rt, pose_quat=q)
+            finally:
+                rasterizer.set_deterministic(False)
+            outs.append([R, color, allmap, radii] + [r for r in res if r is not None])
+        assert outs[0][0] == outs[1][0] > 0
+        for a, b in zip(outs[0][1:], outs[1][1:]):
+            assert torch.equal(a, b)
