@@ -237,8 +237,8 @@ namespace {
 
 // ----------------------------------------------------------------------------------------------------------------------
 // The forward in three phases, so that K frames over the same Gaussians can share ONE blend launch (gs2d_forward_batch):
-//   A  per frame: geometry chunk, preprocess, block-sum scan (its total goes to pinned word `slot`)
-//   B  per frame: image + binning chunks, wait for the frame's num_rendered, duplicate, sort
+//   A  per frame: geometry chunk, preprocess
+//   B  per frame: image + binning chunks, duplicate (its last workgroup sends num_rendered to pinned word `slot`), wait for it, sort
 //   C  once:      blend_fwd over the tiles of all frames, forward records
 // gs2d_forward[_posed] is A, B, C with K = 1.
 struct FwdShared {   // what all frames of a call have in common
@@ -259,7 +259,8 @@ struct FwdFrame {    // one frame: inputs, then the state the phases hand on
     GeomLayout GL; CamParams cam;
     volatile uint32_t* pinned = nullptr;
     bool fused_sort = false;     // the blend kernel sorts this frame's tile lists itself (phase -1)
-    bool store_pending = false;  // the scan kernel WILL store into `pinned`: every return path first waits for that store
+    bool spec = false;           // duplicate runs before the host knows num_rendered (single-pass binning: tiles <= GS2D_BIN_MAX_TILES)
+    bool store_pending = false;  // a kernel WILL store into `pinned`: every return path first waits for that store
     int R = 0;
     gs2d::BlendFwdFrame bf;
 };
@@ -340,16 +341,22 @@ int fwd_phase_a(const FwdShared& c, FwdFrame& f, int slot)
     g_timer.end(ST_PREPROCESS, s);
     GS2D_STAGE("preprocess");
 
-    const int nblk = (c.P + 255) / 256;  // scan_tmp[0..nblk) = per-workgroup sums, then exclusive block offsets
-    uint32_t* total_dev = scan_tmp + nblk + 8;
     // The one host sync of the forward (rasterizer_impl.cu:287): the binning chunk is sized by num_rendered.
-    // Read-back without an OS-level wait and without a copy: the scan stores the total straight into a pinned host word
-    // (system-scope store, issued as soon as the total is known) that was pre-set to a sentinel and is polled in phase B.
-    // On a loaded host a blocking hipStreamSynchronize can cost milliseconds of scheduler latency per call; the poll
-    // returns within a microsecond of the store landing.
+    // Read-back without an OS-level wait and without a copy: the kernel that knows the total first stores it straight into a
+    // pinned host word (system-scope store) that was pre-set to a sentinel and is polled in phase B.  On a loaded host a
+    // blocking hipStreamSynchronize can cost milliseconds of scheduler latency per call; the poll returns within a
+    // microsecond of the store landing.
     // coherent pinned memory: the device's system-scope store must become visible to the polling CPU without a sync
     if (!g_pinned.p) GS2D_CHECK(hipHostMalloc((void**)&g_pinned.p, 64, hipHostMallocCoherent), "hipHostMalloc");
     f.pinned = g_pinned.p + slot;  // 16 words: one per frame of a batch
+    // Single-pass binning (every image up to 4096 tiles): nothing more here -- duplicate_kernel finishes the prefix sum itself
+    // and its last workgroup is the one that stores the total, while the kernel still runs (phase B).  Otherwise (the 8-bit
+    // radix passes place duplicate's output by the pass count's parity, i.e. inside arrays laid out by num_rendered): the
+    // single-workgroup scan of the block sums, which stores the total.
+    f.spec = img_layout(c.width, c.height).tiles <= GS2D_BIN_MAX_TILES;
+    if (f.spec) return 0;
+    const int nblk = (c.P + 255) / 256;  // scan_tmp[0..nblk) = per-workgroup sums, then exclusive block offsets
+    uint32_t* total_dev = scan_tmp + nblk + 8;
     *f.pinned = 0xFFFFFFFFu;
     g_timer.begin(ST_SCAN, s);
     gs2d::launch_offsets_blocksums(c.P, scan_tmp, total_dev, g_pinned.p + slot, s);
@@ -372,7 +379,7 @@ int fwd_phase_b(const FwdShared& c, FwdFrame& f, int slot)
     const GeomLayout& GL = f.GL;
     const CamParams& cam = f.cam;
     const ImgLayout IL = img_layout(width, height);
-    // While the GPU works towards num_rendered, ask for the image chunk and already for the binning chunk, sized from the
+    // While the GPU works on the preprocess, ask for the image chunk and for the binning chunk, the latter sized from the
     // previous call's count for this problem shape (+12.5 %): the allocator callbacks (trips through the caller's runtime)
     // then cost nothing on the critical path.  If the guess turns out too small the callback is simply invoked a second
     // time with the exact size.
@@ -381,24 +388,8 @@ int fwd_phase_b(const FwdShared& c, FwdFrame& f, int slot)
     LastCount& last = g_last[slot];
     const bool same_shape = last.P == P && last.W == width && last.H == height;
     const size_t guess_R = same_shape ? (size_t)last.R + last.R / 8 + 4096 : (size_t)P * 3 + 4096;
+    const int C0 = (int)(guess_R > 0x7fffffffull ? 0x7fffffffull : guess_R);
     const bool det = g_deterministic.load() != 0;
-    const size_t pre_bytes = bin_layout((int)(guess_R > 0x7fffffffull ? 0x7fffffffull : guess_R), det).total;
-    char* bin_pre = (char*)f.binning_alloc(f.binning_user, pre_bytes);
-    if (!wait_total(f, s)) return fail_msg("num_rendered read-back failed");
-    if (debug) GS2D_CHECK(hipStreamSynchronize(s), "scan");
-    const uint32_t num_rendered_u = *f.pinned;
-    if (num_rendered_u == 0xFFFFFFFFu) return fail_msg("num_rendered read-back failed");
-    if (num_rendered_u > 0x7fffffffu) return fail_msg("num_rendered overflows int32");
-    const int R = (int)num_rendered_u;
-    f.R = R;
-
-    last.P = P; last.W = width; last.H = height; last.R = num_rendered_u;
-    const BinLayout BL = bin_layout(R, det);  // offsets always follow the true count; the chunk may be larger than BL.total
-    const bool reuse_pre = bin_pre && BL.total <= pre_bytes;
-    char* bin = reuse_pre ? bin_pre : (char*)f.binning_alloc(f.binning_user, BL.total);
-    if (!bin) return fail_msg("binning allocation failed");
-    f.bin = bin;
-    f.bin_bytes = reuse_pre ? pre_bytes : BL.total;
     char* geom = f.geom;
     char* img = f.img;
     float* depths = (float*)(geom + GL.depths);
@@ -406,6 +397,43 @@ int fwd_phase_b(const FwdShared& c, FwdFrame& f, int slot)
     uint32_t* point_offsets = (uint32_t*)(geom + GL.point_offsets);
     ushort4* rect = (ushort4*)(geom + GL.rect);
     uint32_t* scan_tmp = (uint32_t*)(geom + GL.scan_tmp);
+    // the chunk holds C >= num_rendered instances: only the arrays duplicate_kernel writes are laid out by C (bin_layout)
+    int C = C0;
+    const size_t pre_bytes = bin_layout(C0, det, C0).total;
+    char* bin_pre = (char*)f.binning_alloc(f.binning_user, pre_bytes);
+    if (f.spec) {
+        // duplicate_kernel BEFORE the host knows num_rendered: it writes the unsorted pairs into the guessed chunk (nothing at
+        // or beyond its capacity) and its last workgroup stores the total into the pinned word while the kernel is still running;
+        // the host's reaction -- this poll, the launches below -- overlaps with the kernel instead of following a scan kernel.
+        if (!bin_pre) return fail_msg("binning allocation failed");
+        const BinLayout B0 = bin_layout(C0, det, C0);
+        *f.pinned = 0xFFFFFFFFu;
+        g_timer.begin(ST_DUPLICATE, s);
+        gs2d::launch_duplicate(P, rect, depths, tiles_touched, scan_tmp, 0, point_offsets, cam.gx, (uint64_t*)(bin_pre + B0.keys_alt),
+                               (uint32_t*)(bin_pre + B0.vals_alt), (uint32_t)C0, (uint32_t*)f.pinned, s);
+        g_timer.end(ST_DUPLICATE, s);
+        {
+            const hipError_t le = hipGetLastError();
+            if (le != hipSuccess) return fail("duplicate", le);  // nothing was enqueued: nothing will store into the word
+        }
+        f.store_pending = true;
+    }
+    if (!wait_total(f, s)) return fail_msg("num_rendered read-back failed");
+    if (debug) GS2D_CHECK(hipStreamSynchronize(s), f.spec ? "duplicate" : "scan");
+    const uint32_t num_rendered_u = *f.pinned;
+    if (num_rendered_u == 0xFFFFFFFFu) return fail_msg("num_rendered read-back failed");
+    if (num_rendered_u > 0x7fffffffu) return fail_msg("num_rendered overflows int32");
+    const int R = (int)num_rendered_u;
+    f.R = R;
+
+    last.P = P; last.W = width; last.H = height; last.R = num_rendered_u;
+    const bool reuse_pre = bin_pre && R <= C0;
+    if (!reuse_pre) C = R;
+    const BinLayout BL = bin_layout(R, det, C);  // fixed offsets follow the true count, the unsorted pairs the chunk's capacity
+    char* bin = reuse_pre ? bin_pre : (char*)f.binning_alloc(f.binning_user, BL.total);
+    if (!bin) return fail_msg("binning allocation failed");
+    f.bin = bin;
+    f.bin_bytes = BL.total;
     uint32_t* point_list = (uint32_t*)(bin + BL.point_list);
     uint64_t* keys = (uint64_t*)(bin + BL.keys);
     uint32_t* vals_alt = (uint32_t*)(bin + BL.vals_alt);
@@ -425,9 +453,17 @@ int fwd_phase_b(const FwdShared& c, FwdFrame& f, int slot)
     uint64_t* k_unsorted = (passes & 1) ? keys_alt : keys;
     uint32_t* v_unsorted = (passes & 1) ? vals_alt : point_list;
     // always launched: it also completes point_offsets (all zeros when nothing is visible)
-    g_timer.begin(ST_DUPLICATE, s);
-    gs2d::launch_duplicate(P, rect, depths, tiles_touched, scan_tmp, point_offsets, cam.gx, k_unsorted, v_unsorted, s);
-    g_timer.end(ST_DUPLICATE, s);
+    if (!f.spec) {
+        g_timer.begin(ST_DUPLICATE, s);
+        gs2d::launch_duplicate(P, rect, depths, tiles_touched, scan_tmp, 1, point_offsets, cam.gx, k_unsorted, v_unsorted, 0xFFFFFFFFu,
+                               nullptr, s);
+        g_timer.end(ST_DUPLICATE, s);
+    } else if (!reuse_pre) {
+        // the guess was too small (first call for this shape, or the scene grew by more than 12.5 %): once more, into the
+        // chunk of the right size; the total is known, nothing is published
+        gs2d::launch_duplicate(P, rect, depths, tiles_touched, scan_tmp, 0, point_offsets, cam.gx, k_unsorted, v_unsorted, (uint32_t)C,
+                               nullptr, s);
+    }
     GS2D_STAGE("duplicate");
     if (R > 0) {
         g_timer.begin(ST_SORT, s);
@@ -479,7 +515,6 @@ int fwd_batch_fused(const FwdShared& c, FwdFrame* f, int K)
     cam0.gy = (height + GS2D_TILE - 1) / GS2D_TILE;
     cam0.tight = g_reference_binning.load() == 0;
     if (!g_pinned.p) GS2D_CHECK(hipHostMalloc((void**)&g_pinned.p, 64, hipHostMallocCoherent), "hipHostMalloc");
-    const int nblk = (P + 255) / 256;
     for (int k = 0; k < K; k++) {
         if (!f[k].geometry_alloc || !f[k].binning_alloc || !f[k].image_alloc) return fail_msg("allocator callbacks are required");
         f[k].GL = GL;
@@ -496,10 +531,8 @@ int fwd_batch_fused(const FwdShared& c, FwdFrame* f, int K)
         q.clamped = (uint8_t*)(geom + GL.clamped); q.block_sums = (uint32_t*)(geom + GL.scan_tmp);
         gs2d::BinFrame& b = bin.f[k];
         b.rect = q.rect; b.depths = q.depths; b.tiles_touched = q.tiles_touched; b.block_sums = q.block_sums;
-        b.total_dev = q.block_sums + nblk + 8;
         f[k].pinned = g_pinned.p + k;
-        *f[k].pinned = 0xFFFFFFFFu;
-        b.total_host = g_pinned.p + k;
+        f[k].spec = true;
         b.point_offsets = (uint32_t*)(geom + GL.point_offsets);
         b.R = 0; b.nblocks = 0;
     }
@@ -509,50 +542,68 @@ int fwd_batch_fused(const FwdShared& c, FwdFrame* f, int K)
                                       c.transMat_precomp, c.colors_precomp, cam0, pre, s);
     g_timer.end(ST_PREPROCESS, s);
     GS2D_STAGE("preprocess (batch)");
-    g_timer.begin(ST_SCAN, s);
-    gs2d::launch_offsets_blocksums_batch(P, K, bin, s);
-    g_timer.end(ST_SCAN, s);
-    {
-        const hipError_t le = hipGetLastError();
-        if (le != hipSuccess) return fail("scan (batch)", le);  // nothing was enqueued: nothing will store into the words
-    }
-    for (int k = 0; k < K; k++) f[k].store_pending = true;
-    // while the GPU works towards the K totals: image chunks and, from the previous call's counts, the binning chunks
+    // while the GPU works on the preprocess: image chunks and, sized from the previous call's counts, the binning chunks; then
+    // duplicate for all K frames BEFORE the host knows the K totals (see fwd_phase_b): each frame's last workgroup stores its own
     const bool det = g_deterministic.load() != 0;
     char* bin_pre[GS2D_MAX_BATCH];
-    size_t pre_bytes[GS2D_MAX_BATCH];
+    int cap[GS2D_MAX_BATCH];
     for (int k = 0; k < K; k++) {
         f[k].img = (char*)f[k].image_alloc(f[k].image_user, IL.total);
         if (!f[k].img) return fail_msg("image allocation failed");
         LastCount& last = g_last[k];
         const bool same_shape = last.P == P && last.W == width && last.H == height;
         const size_t guess_R = same_shape ? (size_t)last.R + last.R / 8 + 4096 : (size_t)P * 3 + 4096;
-        pre_bytes[k] = bin_layout((int)(guess_R > 0x7fffffffull ? 0x7fffffffull : guess_R), det).total;
-        bin_pre[k] = (char*)f[k].binning_alloc(f[k].binning_user, pre_bytes[k]);
+        cap[k] = (int)(guess_R > 0x7fffffffull ? 0x7fffffffull : guess_R);
+        const BinLayout B0 = bin_layout(cap[k], det, cap[k]);
+        bin_pre[k] = (char*)f[k].binning_alloc(f[k].binning_user, B0.total);
+        if (!bin_pre[k]) return fail_msg("binning allocation failed");
+        gs2d::BinFrame& b = bin.f[k];
+        b.keys_unsorted = (uint64_t*)(bin_pre[k] + B0.keys_alt); b.vals_unsorted = (uint32_t*)(bin_pre[k] + B0.vals_alt);
+        b.capacity = (uint32_t)cap[k];
+        b.total_host = (uint32_t*)f[k].pinned;
+        *f[k].pinned = 0xFFFFFFFFu;
     }
+    for (int k = K; k < GS2D_MAX_BATCH; k++) bin.f[k] = bin.f[0];
+    g_timer.begin(ST_DUPLICATE, s);
+    gs2d::launch_duplicate_batch(P, K, cam0.gx, bin, s);
+    g_timer.end(ST_DUPLICATE, s);
+    {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return fail("duplicate (batch)", le);  // nothing was enqueued: nothing will store into the words
+    }
+    for (int k = 0; k < K; k++) f[k].store_pending = true;
     const int tile_bits = (int)higher_msb((uint32_t)(cam0.gx * cam0.gy));
+    bool redo = false;
     for (int k = 0; k < K; k++) {
         if (!wait_total(f[k], s)) return fail_msg("num_rendered read-back failed");
         const uint32_t num_rendered_u = *f[k].pinned;
         if (num_rendered_u == 0xFFFFFFFFu) return fail_msg("num_rendered read-back failed");
         if (num_rendered_u > 0x7fffffffu) return fail_msg("num_rendered overflows int32");
-        const int R = (int)num_rendered_u;
-        f[k].R = R;
+        f[k].R = (int)num_rendered_u;
         LastCount& last = g_last[k];
         last.P = P; last.W = width; last.H = height; last.R = num_rendered_u;
-        const BinLayout BL = bin_layout(R, det);
-        const bool reuse_pre = bin_pre[k] && BL.total <= pre_bytes[k];
-        char* bn = reuse_pre ? bin_pre[k] : (char*)f[k].binning_alloc(f[k].binning_user, BL.total);
-        if (!bn) return fail_msg("binning allocation failed");
+        redo = redo || f[k].R > cap[k];
+    }
+    for (int k = 0; k < K; k++) {
+        const int R = f[k].R;
+        char* bn = bin_pre[k];
+        if (R > cap[k]) {  // this frame's guess was too small: a chunk of the exact size
+            cap[k] = R;
+            bn = (char*)f[k].binning_alloc(f[k].binning_user, bin_layout(R, det, R).total);
+            if (!bn) return fail_msg("binning allocation failed");
+        }
+        const BinLayout BL = bin_layout(R, det, cap[k]);
         f[k].bin = bn;
-        f[k].bin_bytes = reuse_pre ? pre_bytes[k] : BL.total;
+        f[k].bin_bytes = BL.total;
         gs2d::BinFrame& b = bin.f[k];
+        b.capacity = (uint32_t)cap[k];
+        b.total_host = nullptr;
         b.R = R;
         b.point_list = (uint32_t*)(bn + BL.point_list);
         b.keys = (uint64_t*)(bn + BL.keys);
         b.vals_alt = (uint32_t*)(bn + BL.vals_alt);
         b.keys_alt = (uint64_t*)(bn + BL.keys_alt);
-        // one counting-sort pass: the unsorted pairs start in the "alt" buffers so that the result lands in (keys, point_list)
+        // one counting-sort pass: the unsorted pairs sit in the "alt" buffers so that the result lands in (keys, point_list)
         b.keys_unsorted = b.keys_alt; b.vals_unsorted = b.vals_alt;
         b.hist = (uint32_t*)(bn + BL.hist);
         b.ranges = (uint2*)(f[k].img + IL.ranges);
@@ -563,8 +614,12 @@ int fwd_batch_fused(const FwdShared& c, FwdFrame* f, int K)
         o.zero = (float4*)(f[k].geom + GL.grad_rec);
         o.keys = b.keys; o.keys_alt = b.keys_alt; o.vals_alt = b.vals_alt;
     }
-    if (debug) GS2D_CHECK(hipStreamSynchronize(s), "scan (batch)");
+    if (debug) GS2D_CHECK(hipStreamSynchronize(s), "duplicate (batch)");
     for (int k = K; k < GS2D_MAX_BATCH; k++) bin.f[k] = bin.f[0];
+    if (redo) {  // (rare: first call for this shape, or a scene that grew by more than 12.5 %) all frames once more, nothing published
+        gs2d::launch_duplicate_batch(P, K, cam0.gx, bin, s);
+        GS2D_STAGE("duplicate (batch, second launch)");
+    }
     long long max_R = 0;
     bool any_empty = false;
     for (int k = 0; k < K; k++) { max_R = f[k].R > max_R ? f[k].R : max_R; any_empty = any_empty || f[k].R == 0; }
@@ -574,7 +629,7 @@ int fwd_batch_fused(const FwdShared& c, FwdFrame* f, int K)
     g_timer.begin(ST_SORT, s);
     gs2d::launch_bin_sort_batch(P, K, IL.tiles, cam0.gx, tile_bits, bin, debug ? 1 : 0, /*depth_sort=*/!fused_sort, s);
     g_timer.end(ST_SORT, s);
-    GS2D_STAGE("duplicate + sort (batch)");
+    GS2D_STAGE("sort (batch)");
     return 0;
 }
 

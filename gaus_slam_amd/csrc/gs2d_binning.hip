@@ -32,11 +32,6 @@ __global__ void __launch_bounds__(SCAN_T) scan_blocksums_kernel(uint32_t* __rest
 }
 // Batched forms (gs2d_forward_batch): blockIdx.y = frame, per-frame pointers from a by-value table in the kernel arguments;
 // the bodies are the single-frame kernels' own.
-__global__ void __launch_bounds__(SCAN_T) scan_blocksums_batch_kernel(int nblocks, const gs2d::BinFrames tab)
-{
-    const gs2d::BinFrame& f = tab.f[blockIdx.y];
-    scan_blocksums_body(f.block_sums, nblocks, f.total_dev, f.total_host);
-}
 
 __global__ void __launch_bounds__(SCAN_T) scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n,
                                                             const uint32_t* __restrict__ block_offsets)
@@ -71,23 +66,46 @@ __device__ __forceinline__ int f2i_sat(float v)
 // from the preprocess kernel (the reference's, or its intersection with the footprint bound), not re-derived from radii.
 __device__ __forceinline__ void
 duplicate_body(int P, const ushort4* __restrict__ rect, const float* __restrict__ depths,
-               const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_offsets,
-               uint32_t* __restrict__ point_offsets, int gx, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+               const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_sums, int scanned,
+               uint32_t* __restrict__ point_offsets, int gx, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+               uint32_t capacity, uint32_t* __restrict__ total_host)
 {
     // The prefix sum of tiles_touched (rasterizer_impl.cu:283) is finished here: the preprocess kernel left one sum per
-    // 256 Gaussians, scan_blocksums_kernel turned those into exclusive block offsets, and this workgroup (the same 256
-    // Gaussians) adds its own inclusive scan -- no separate scan-apply launch.
+    // 256 Gaussians; this workgroup (the same 256 Gaussians) adds up the sums of the blocks before it -- at most a few
+    // thousand cached words, eight per thread at 500k Gaussians -- and its own inclusive scan on top.  No scan kernel (until
+    // round 3 a single-workgroup kernel scanned the block sums first and stored the total for the host: 4-7 us plus a
+    // dependent dispatch on the critical path of every forward; it remains for the callers that need the total up front,
+    // `scanned`).  The last block's offset plus its own sum IS the total: it goes to the host from here.
+    uint32_t before = 0;
+    if (!scanned)
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += block_sums[b];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int ci = min(idx, P - 1);
     const uint32_t mine = idx < P ? tiles_touched[ci] : 0u;
     // everything the emit loop needs is requested before the workgroup scan, whose two barriers then hide the latency
     const ushort4 r = rect[ci];
     const uint32_t dbits = __float_as_uint(depths[ci]);
-    const uint32_t incl = block_offsets[blockIdx.x] + block_incl_scan(mine, nullptr);
+    uint32_t block_offset, own_total;
+    if (scanned) block_offset = block_sums[blockIdx.x];
+    else (void)block_incl_scan(before, &block_offset);
+    const uint32_t incl = block_offset + block_incl_scan(mine, &own_total);
+    if (!scanned && total_host != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        // a relaxed system-scope store into coherent pinned memory: the host polls the word (0xFFFFFFFF = not yet)
+        const uint32_t total = block_offset + own_total;
+        __hip_atomic_store(total_host, total == 0xFFFFFFFFu ? 0xFFFFFFFEu : total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (idx >= P) return;
     point_offsets[idx] = incl;  // inclusive offsets, as the reference's InclusiveSum leaves them
     if (mine == 0u) return;
     uint32_t off = incl - mine;
+    if (incl > capacity) {  // the caller's guess was too small: it will launch again with room for everything (rare)
+        for (uint32_t y = r.y; y < r.w; y++)
+            for (uint32_t x = r.x; x < r.z; x++) {
+                if (off < capacity) { keys[off] = ((uint64_t)(y * (uint32_t)gx + x) << 32) | dbits; vals[off] = (uint32_t)idx; }
+                off++;
+            }
+        return;
+    }
     for (uint32_t y = r.y; y < r.w; y++)
         for (uint32_t x = r.x; x < r.z; x++) {
             const uint64_t key = ((uint64_t)(y * (uint32_t)gx + x) << 32) | dbits;
@@ -98,15 +116,17 @@ duplicate_body(int P, const ushort4* __restrict__ rect, const float* __restrict_
 }
 __global__ void __launch_bounds__(256)
 duplicate_kernel(int P, const ushort4* __restrict__ rect, const float* __restrict__ depths,
-                 const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_offsets,
-                 uint32_t* __restrict__ point_offsets, int gx, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+                 const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_sums, int scanned,
+                 uint32_t* __restrict__ point_offsets, int gx, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                 uint32_t capacity, uint32_t* __restrict__ total_host)
 {
-    duplicate_body(P, rect, depths, tiles_touched, block_offsets, point_offsets, gx, keys, vals);
+    duplicate_body(P, rect, depths, tiles_touched, block_sums, scanned, point_offsets, gx, keys, vals, capacity, total_host);
 }
 __global__ void __launch_bounds__(256) duplicate_batch_kernel(int P, int gx, const gs2d::BinFrames tab)
 {
     const gs2d::BinFrame& f = tab.f[blockIdx.y];
-    duplicate_body(P, f.rect, f.depths, f.tiles_touched, f.block_sums, f.point_offsets, gx, f.keys_unsorted, f.vals_unsorted);
+    duplicate_body(P, f.rect, f.depths, f.tiles_touched, f.block_sums, 0, f.point_offsets, gx, f.keys_unsorted, f.vals_unsorted,
+                   f.capacity, f.total_host);
 }
 
 // ---------------------------------------------------------------- radix sort pass (8-bit digit)
@@ -404,11 +424,11 @@ void launch_offsets_blocksums(int P, uint32_t* block_sums, uint32_t* total_dev, 
 }
 
 void launch_duplicate(int P, const ushort4* rect, const float* depths, const uint32_t* tiles_touched,
-                      const uint32_t* block_offsets, uint32_t* point_offsets, int gx, uint64_t* keys, uint32_t* vals,
-                      hipStream_t s)
+                      const uint32_t* block_sums, int scanned, uint32_t* point_offsets, int gx, uint64_t* keys, uint32_t* vals,
+                      uint32_t capacity, uint32_t* total_host, hipStream_t s)
 {
-    hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, rect, depths, tiles_touched, block_offsets,
-                       point_offsets, gx, keys, vals);
+    hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, rect, depths, tiles_touched, block_sums, scanned,
+                       point_offsets, gx, keys, vals, capacity, total_host);
 }
 
 void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int begin_bit,
@@ -467,12 +487,12 @@ void launch_tile_depth_sort(int R, int tiles, const uint2* ranges, uint64_t* key
                        vals_alt, cap, packed, write_keys);
 }
 
-void launch_offsets_blocksums_batch(int P, int K, const BinFrames& tab, hipStream_t s)
+void launch_duplicate_batch(int P, int K, int gx, const BinFrames& tab, hipStream_t s)
 {
-    hipLaunchKernelGGL(scan_blocksums_batch_kernel, dim3(1, K), dim3(SCAN_T), 0, s, (P + 255) / 256, tab);
+    hipLaunchKernelGGL(duplicate_batch_kernel, dim3((P + 255) / 256, K), dim3(256), 0, s, P, gx, tab);
 }
 
-// duplicate + the single-pass tile binning + the per-tile depth sort for K frames, five launches in all (tiles <= GS2D_BIN_MAX_TILES)
+// the single-pass tile binning + the per-tile depth sort for K frames (tiles <= GS2D_BIN_MAX_TILES; launch_duplicate_batch ran before)
 void launch_bin_sort_batch(int P, int K, int tiles, int gx, int nbits, BinFrames& tab, int write_keys, bool depth_sort, hipStream_t s)
 {
     int max_blocks = 0;
@@ -483,7 +503,7 @@ void launch_bin_sort_batch(int P, int K, int tiles, int gx, int nbits, BinFrames
         max_R = tab.f[k].R > max_R ? tab.f[k].R : max_R;
         if (tab.f[k].R == 0) (void)hipMemsetAsync(tab.f[k].ranges, 0, sizeof(uint2) * (size_t)tiles, s);  // nothing will write them
     }
-    hipLaunchKernelGGL(duplicate_batch_kernel, dim3((P + 255) / 256, K), dim3(256), 0, s, P, gx, tab);
+    (void)P; (void)gx;
     if (max_blocks == 0) return;
     hipLaunchKernelGGL(bin_hist_batch_kernel, dim3(max_blocks, K), dim3(BIN_T), (size_t)tiles * 4, s, tiles, tab);
     hipLaunchKernelGGL(bin_row_scan_batch_kernel, dim3((tiles + 3) / 4, K), dim3(256), 0, s, tiles, tab);

@@ -68,34 +68,49 @@ static inline GeomLayout geom_layout(int P)
     return L;
 }
 
+// The binning chunk.  Everything that is read after the forward's duplicate step -- by the rest of the forward, by the backward,
+// by the debug readers -- sits at offsets that depend on num_rendered (R) alone.  Only the two arrays duplicate_kernel writes
+// (the unsorted pairs: keys_alt, vals_alt) follow a CAPACITY C >= R: the forward launches that kernel before the host knows R
+// (gs2d_api.hip, fwd_phase_b), into a chunk sized for C instances, so their offsets must not depend on R.  C < 0: C = R, the
+// layout a caller who knows R computes (gs2d_binning_bytes; the backward, which never touches the two arrays).
 // det: also room for the deterministic backward (inverse permutation + one partial gradient record per (instance, quadrant))
-static inline BinLayout bin_layout(int R, bool det = false)
+static inline BinLayout bin_layout(int R, bool det = false, int C = -1)
 {
     BinLayout L;
-    size_t o = 0;
     const size_t r = (size_t)(R > 0 ? R : 1);
-    L.point_list = o; o = gs2d_align_up(o + 4 * r, 256);
-    // phase 0 of blend_fwd -> both blend kernels: per instance and quadrant, the 16 group bits of the cull test (u16 each)
-    L.hits = o; o = gs2d_align_up(o + 8 * r, 256);
-    // the same bits ORed down to the four 4x4 sub-blocks of each quadrant (one byte per quadrant): what the backward's
-    // four row queues are built from
-    L.hits4 = o; o = gs2d_align_up(o + 4 * r, 256);
-    L.keys = o; o = gs2d_align_up(o + 8 * r, 256);
-    L.vals_alt = o; o = gs2d_align_up(o + 4 * r, 256);
-    L.keys_alt = o; o = gs2d_align_up(o + 8 * r, 256);
-    const size_t nblk = (r + GS2D_SORT_ITEMS - 1) / GS2D_SORT_ITEMS;
-    L.hist_elems = 256 * nblk;
-    // the single-pass tile binning needs tiles x ceil(R / GS2D_BIN_ITEMS) counters; size for the larger of the two
-    const size_t bin_elems = (size_t)GS2D_BIN_MAX_TILES * ((r + GS2D_BIN_ITEMS - 1) / GS2D_BIN_ITEMS);
-    const size_t cap_elems = L.hist_elems > bin_elems ? L.hist_elems : bin_elems;
-    const size_t scan_blk = (cap_elems + GS2D_SCAN_ITEMS - 1) / GS2D_SCAN_ITEMS;
-    // (+ GS2D_BIN_MAX_TILES: the per-tile totals of the binning pass sit behind its counters)
-    L.hist = o; o = gs2d_align_up(o + 4 * (cap_elems + scan_blk + 64 + GS2D_BIN_MAX_TILES), 256);
-    L.det_inv = o; L.det_slots = o;
-    if (det) {
-        o = gs2d_align_up(o + 4 * r, 256);
-        L.det_slots = o; o = gs2d_align_up(o + 4 * (size_t)GS2D_GRAD_FLOATS * 4 * r, 256);
-    }
+    const size_t c = (C >= 0 && (size_t)C > r) ? (size_t)C : r;
+    auto fixed_part = [det](size_t n, BinLayout* out) -> size_t {
+        size_t o = 0;
+        const size_t point_list = o; o = gs2d_align_up(o + 4 * n, 256);
+        // phase 0 of blend_fwd -> both blend kernels: per instance and quadrant, the 16 group bits of the cull test (u16 each)
+        const size_t hits = o; o = gs2d_align_up(o + 8 * n, 256);
+        // the same bits ORed down to the four 4x4 sub-blocks of each quadrant (one byte per quadrant): what the backward's
+        // four row queues are built from
+        const size_t hits4 = o; o = gs2d_align_up(o + 4 * n, 256);
+        const size_t keys = o; o = gs2d_align_up(o + 8 * n, 256);
+        const size_t nblk = (n + GS2D_SORT_ITEMS - 1) / GS2D_SORT_ITEMS;
+        const size_t hist_elems = 256 * nblk;
+        // the single-pass tile binning needs tiles x ceil(R / GS2D_BIN_ITEMS) counters; size for the larger of the two
+        const size_t bin_elems = (size_t)GS2D_BIN_MAX_TILES * ((n + GS2D_BIN_ITEMS - 1) / GS2D_BIN_ITEMS);
+        const size_t cap_elems = hist_elems > bin_elems ? hist_elems : bin_elems;
+        const size_t scan_blk = (cap_elems + GS2D_SCAN_ITEMS - 1) / GS2D_SCAN_ITEMS;
+        // (+ GS2D_BIN_MAX_TILES: the per-tile totals of the binning pass sit behind its counters)
+        const size_t hist = o; o = gs2d_align_up(o + 4 * (cap_elems + scan_blk + 64 + GS2D_BIN_MAX_TILES), 256);
+        size_t det_inv = o, det_slots = o;
+        if (det) {
+            o = gs2d_align_up(o + 4 * n, 256);
+            det_slots = o; o = gs2d_align_up(o + 4 * (size_t)GS2D_GRAD_FLOATS * 4 * n, 256);
+        }
+        if (out) {
+            out->point_list = point_list; out->hits = hits; out->hits4 = hits4; out->keys = keys; out->hist = hist;
+            out->hist_elems = hist_elems; out->det_inv = det_inv; out->det_slots = det_slots;
+        }
+        return o;
+    };
+    (void)fixed_part(r, &L);
+    size_t o = fixed_part(c, nullptr);  // the capacity-sized arrays start where the fixed part of a FULL chunk would end
+    L.vals_alt = o; o = gs2d_align_up(o + 4 * c, 256);
+    L.keys_alt = o; o = gs2d_align_up(o + 8 * c, 256);
     L.total = o;
     return L;
 }
@@ -187,13 +202,18 @@ void launch_pose_quat(const float* pose_Rt, float* q_out, hipStream_t s);
 // total_host (optional): pinned host word that receives the total with a system-scope store as soon as it is known.
 void launch_inclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* tmp, uint32_t* total_out, hipStream_t s,
                            uint32_t* total_host = nullptr);
-// prefix sum of tiles_touched in three fused steps: launch_preprocess_fwd leaves one sum per 256 Gaussians in
-// block_sums; launch_offsets_blocksums scans them in place (exclusive) and publishes the total (device word + optional
-// pinned host word, system-scope store); launch_duplicate adds each block's own scan and writes point_offsets.
+// prefix sum of tiles_touched: launch_preprocess_fwd leaves one sum per 256 Gaussians in block_sums.
+//  * scanned == 0 (the normal path): launch_duplicate adds up the sums of the blocks before each block itself, its own scan on
+//    top, writes point_offsets, and its LAST block stores the grand total (num_rendered) into the pinned host word total_host
+//    (if given) as soon as it knows it -- while the kernel is still running.  No instance at or beyond `capacity` is written:
+//    the caller launches this before it knows the total, into arrays sized from a guess, and repeats the launch with the exact
+//    size when the guess was too small.
+//  * scanned != 0: block_sums already holds exclusive block offsets (launch_offsets_blocksums, which also publishes the total):
+//    the path of callers that must know the total before they can place the output.
 void launch_offsets_blocksums(int P, uint32_t* block_sums, uint32_t* total_dev, uint32_t* total_host, hipStream_t s);
 void launch_duplicate(int P, const ushort4* rect, const float* depths, const uint32_t* tiles_touched,
-                      const uint32_t* block_offsets, uint32_t* point_offsets, int gx, uint64_t* keys, uint32_t* vals,
-                      hipStream_t s);
+                      const uint32_t* block_sums, int scanned, uint32_t* point_offsets, int gx, uint64_t* keys, uint32_t* vals,
+                      uint32_t capacity, uint32_t* total_host, hipStream_t s);
 // stable LSD radix sort of (u64 key, u32 val) pairs on key bits [begin_bit, end_bit). Result lands in keys_a/vals_a;
 // the unsorted input must sit in the "b" buffers when the pass count ceil((end-begin)/8) is odd, else in "a".
 void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int begin_bit,
@@ -233,8 +253,9 @@ void launch_sum_frames(int P, int K, int M, const PreBwdFrames& tab, hipStream_t
 // Per-frame pointers of the binning chain (duplicate, tile binning, depth sort) in the batched forward.
 struct BinFrame {
     const ushort4* rect; const float* depths; const uint32_t* tiles_touched;
-    uint32_t* block_sums;      // per-256-Gaussian sums of tiles_touched -> exclusive block offsets (scan_blocksums)
-    uint32_t* total_dev; uint32_t* total_host;
+    const uint32_t* block_sums; // per-256-Gaussian sums of tiles_touched (preprocess)
+    uint32_t* total_host;       // pinned host word for num_rendered (NULL: do not publish); capacity: instances the unsorted arrays hold
+    uint32_t capacity;
     uint32_t* point_offsets;
     uint64_t* keys_unsorted; uint32_t* vals_unsorted;   // duplicate's output
     uint64_t* keys; uint32_t* point_list;                // binned (packed pairs) -> sorted ids
@@ -244,7 +265,7 @@ struct BinFrame {
     int R, nblocks;
 };
 struct BinFrames { BinFrame f[8]; };
-void launch_offsets_blocksums_batch(int P, int K, const BinFrames& tab, hipStream_t s);
+void launch_duplicate_batch(int P, int K, int gx, const BinFrames& tab, hipStream_t s);
 // depth_sort = false: stop after the scatter (the forward blend kernel then sorts every tile's list as its first phase)
 void launch_bin_sort_batch(int P, int K, int tiles, int gx, int nbits, BinFrames& tab, int write_keys, bool depth_sort, hipStream_t s);
 // LDS capacity (elements) launch_tile_depth_sort picks for R instances on `tiles` tiles: 1536 / 2048 / 3072 / 4096

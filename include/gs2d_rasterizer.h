@@ -59,7 +59,10 @@ extern "C" {
 
 /* Scratch allocator: must return a device pointer to >= `bytes` bytes, 256-byte aligned.  A callback may be invoked more
  * than once per call (the binning chunk is requested early from an estimate and again if that was too small); only the
- * pointer returned LAST is used, and the chunk may be larger than the library strictly needs. */
+ * pointer returned LAST is handed on to the backward, and the chunk may be larger than the library strictly needs.  A kernel
+ * enqueued on `stream` may still write into the EARLIER chunk when the later request arrives (the forward fills the estimated
+ * chunk before it knows num_rendered): an allocator that recycles the earlier chunk must do so in the order of that stream,
+ * as a stream-ordered allocator (torch's caching allocator, hipMallocAsync / hipFreeAsync on `stream`) does by itself. */
 typedef void* (*gs2d_alloc_fn)(void* user, size_t bytes);
 
 /* Returns num_rendered (>= 0, number of (tile, Gaussian) instances) or < 0 on error.

@@ -294,3 +294,59 @@ def test_k_keyframe_policy_reaches_the_one_keyframe_loss():
     assert l_k2 <= 1.05 * l_ref
     assert l_k2_same <= 1.01 * l_ref
     assert abs(l_k2_mean - l_k2_same) <= 2e-3 * l_k2_same
+
+
+def _grow_scene(P, W, H, seed, scale_hi):
+    from gaus_slam_amd.scene_synth import make_scene
+    return make_scene(P, W, H, seed=seed, regime="mapping", scale_lo=0.3, scale_hi=scale_hi)
+
+
+def test_duplicate_before_num_rendered_guess_too_small_and_large_enough(oracle):
+    """duplicate_kernel runs before the host knows num_rendered, into a binning chunk sized from the previous call of the same
+    problem shape (+12.5 %), and sends the total to the host from its last workgroup (gs2d_api.hip, fwd_phase_b).  Same shape,
+    growing and shrinking scenes: a call whose guess was too small (second launch into an exact-size chunk) and a call whose
+    guess was generous give the lists, ranges and images of the oracle, bit for bit, and their gradients agree with a call
+    whose guess fitted."""
+    W, H, P = 320, 240, 6000
+    small, big = _grow_scene(P, W, H, 41, 1.0), _grow_scene(P, W, H, 42, 12.0)
+    o_small, o_big = util.oracle_forward(oracle, small, use_sa=True), util.oracle_forward(oracle, big, use_sa=True)
+    assert o_big["num_rendered"] > 1.125 * o_small["num_rendered"] + 4096 > 0  # the small scene's count is too small a guess
+    dc, da = util.make_upstream_grads(W, H, channels=(0, 1, 5, 6))
+    dc, da = (dc * W * H).numpy(), (da * W * H).numpy()
+    grads = {}
+    for name, sc, o in (("small", small, o_small), ("big after small: guess too small", big, o_big), ("big after big: fits", big, o_big),
+                        ("small after big: generous", small, o_small)):
+        h = util.hip_forward(sc, use_sa=True)
+        assert h["num_rendered"] == o["num_rendered"], name
+        np.testing.assert_array_equal(h["point_list"], o["point_list"], err_msg=name)
+        np.testing.assert_array_equal(h["ranges"], o["ranges"], err_msg=name)
+        np.testing.assert_array_equal(h["point_offsets"], o["point_offsets"], err_msg=name)
+        stable = (o["stability"] > KNIFE).reshape(H, W)
+        assert np.abs(h["color"] - o["color"])[:, stable].max() <= IMG_TOL, name
+        grads[name] = util.hip_backward(h, dc, da)
+    for k in ALL_GRADS:
+        a, b = grads["big after small: guess too small"][k], grads["big after big: fits"][k]
+        assert util.grad_err(a, b) <= 1e-6, k  # (float atomics: equal up to the order of the additions)
+
+
+def test_duplicate_before_num_rendered_in_a_batch():
+    """The batched forward launches duplicate for all K frames before the host knows the K totals; a frame whose guess was too
+    small makes the batch launch it a second time.  Frames of a batch equal the same frames rendered one call at a time."""
+    from gaus_slam_amd import render as gs_render
+    from gaus_slam_amd.scene_synth import random_w2c, setup_camera
+    W, H, P = 320, 240, 6000
+    dev = torch.device("cuda")
+    for scale_hi in (1.0, 12.0, 2.0):  # per-slot guesses: grow (second launch), then shrink
+        sc = _grow_scene(P, W, H, 43, scale_hi)
+        p = {k: sc[k].to(dev) for k in ("means3D", "opacities", "scales", "rotations", "colors")}
+        cams = [sc["cam"]] + [setup_camera(W, H, sc["cam"].K, random_w2c(np.random.default_rng(50 + i), 3.0, 0.1) @ sc["cam"].w2c)
+                              for i in range(2)]
+        sts = [gs_render.settings_from_camera(c, dev, use_sa=True) for c in cams]
+        m2 = torch.zeros_like(p["means3D"])
+        pk_b = gs_render.render_batch(sts, p["means3D"], m2, p["opacities"], colors_precomp=p["colors"], scales=p["scales"],
+                                      rotations=p["rotations"])
+        for st, pb in zip(sts, pk_b):
+            pk = gs_render.render(st, p["means3D"], m2, p["opacities"], colors_precomp=p["colors"], scales=p["scales"],
+                                  rotations=p["rotations"])
+            assert torch.equal(pk["render_color"], pb["render_color"]) and torch.equal(pk["allmap"], pb["allmap"])
+            assert torch.equal(pk["radius"], pb["radius"])
