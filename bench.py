@@ -487,6 +487,10 @@ def slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world):
         one = torch.ones((), dtype=torch.float32, device=dev)  # seed of loss.backward(): not re-filled in every iteration
 
         def one_step():
+            with torch.autograd.set_multithreading_enabled(False):  # backward in the calling thread (ba_shard.local_backward)
+                _tracking_step()
+
+        def _tracking_step():
             opt.zero_grad(set_to_none=True)
             pkg = tracking.render_tracking(settings, w2c, p["means3D"], p["opacities"], p["colors"], p["scales"], p["rotations"])
             if args.loss_autograd:

@@ -9,6 +9,7 @@ scene/Gaussians.py:124-135) and summed with a single all-reduce.  World size 1 s
 reproduces the single-GPU path bit for bit.
 """
 import contextlib
+import os
 from collections import OrderedDict
 
 import torch
@@ -84,6 +85,7 @@ class GradBucket:
 
 
 MAX_BATCH_KEYFRAMES = 8  # GS2D_MAX_FRAMES
+_ENGINE_THREADS = os.environ.get("GS2D_AUTOGRAD_ENGINE_THREADS", "0") == "1"  # dev A/B switch, see local_backward
 
 
 def k_keyframe_schedule(K, reference_steps, reference_lrs):
@@ -161,7 +163,10 @@ class KeyframeShardedBA:
         if sink is not None:
             from . import rasterizer
             ctx = rasterizer.grad_sink(sink, chunk_rows=chunk_rows, on_chunk=on_chunk)
-        with ctx:
+        # The autograd engine hands CUDA-device nodes to a worker thread and blocks on a future: two thread wake-ups per backward,
+        # 100-180 us of host time per step on the GPU boxes (scripts/dev/host_overhead_mt.py: 329 -> 148 us per fwd+bwd step) --
+        # more than the launches themselves.  One device, one graph: run the backward in the calling thread.
+        with ctx, torch.autograd.set_multithreading_enabled(_ENGINE_THREADS):
             if isinstance(res, tuple):
                 outs, ups = res
                 torch.autograd.backward(list(outs), list(ups))
