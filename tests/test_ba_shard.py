@@ -9,6 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from gaus_slam_amd import ba_shard
+from tests import util
 
 
 def _params(P, seed=0):
@@ -49,7 +50,7 @@ def _worker(rank, world, port, P, keyframes, q):
 
 @pytest.mark.parametrize("keyframes", [[0, 1], [0, 1, 2], [5]])
 def test_world2_equals_serial_sum(keyframes):
-    P, world, port = 257, 2, 29513 + len(keyframes)
+    P, world, port = 257, 2, util.free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, P, keyframes, q)) for r in range(world)]
@@ -105,7 +106,7 @@ def _worker_chunks(rank, world, port, P, q):
 def test_chunked_reduce_rows_and_frame_param_gather():
     """GradBucket.reduce_rows / wait (per-chunk coalesced all-reduce of the five field slices) sums exactly like one
     all-reduce of the whole bucket, and gather_frame_params all-gathers the 9 rank-local pose / exposure scalars."""
-    P, world, port = 257, 2, 29533
+    P, world, port = 257, 2, util.free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker_chunks, args=(r, world, port, P, q)) for r in range(world)]

@@ -12,6 +12,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests import util
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -86,7 +88,7 @@ def test_two_ranks_real_rasterizer_direct_grads_chunked_allreduce():
         script, out = os.path.join(td, "child.py"), os.path.join(td, "out.npz")
         with open(script, "w") as f:
             f.write(CHILD)
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", WORLD_SIZE="2")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(util.free_port()), WORLD_SIZE="2")
         procs = [subprocess.Popen([sys.executable, script, ROOT, out], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                                   stderr=subprocess.STDOUT, text=True) for r in range(2)]
         logs = [p.communicate(timeout=600)[0] for p in procs]
@@ -163,7 +165,7 @@ def test_one_rank_rccl_runs_the_multi_gpu_code_path():
         script, out = os.path.join(td, "child.py"), os.path.join(td, "out.npz")
         with open(script, "w") as f:
             f.write(RCCL_CHILD)
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29573", WORLD_SIZE="1", RANK="0",
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(util.free_port()), WORLD_SIZE="1", RANK="0",
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         p = subprocess.run([sys.executable, script, ROOT, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                            text=True, timeout=600)

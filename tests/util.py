@@ -190,3 +190,12 @@ def check_knife_pixels(orc, o, h, stable, tol, knife, scale=None):
         worst = max(worst, best)
     print(f"knife-edge pixels: {len(ys)} of {HW} ({len(ys) / HW:.2e}), all matched an oracle outcome, max err {worst:.2e}")
     return len(ys), worst
+
+
+def free_port():
+    """A TCP port that is free right now on 127.0.0.1 (rendezvous of the multi-process tests: a fixed port fails when two runs of
+    the suite overlap, or when the previous run's socket is still in TIME_WAIT)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
