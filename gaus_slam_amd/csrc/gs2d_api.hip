@@ -277,10 +277,9 @@ int fwd_validate(const FwdShared& c)
     return 0;
 }
 
-// Poll, then yield: the store normally lands within tens of microseconds (preprocess + block-sum scan), so the thread spins
-// with `pause` for at most ~100 us; if the stream is backed up behind earlier work (or several ranks share the host's cores)
-// it hands its time slice back between looks instead of burning a core per rank.  Falls back to a real synchronise after
-// ~2 s (surfacing any GPU error).
+// Poll, then yield: the thread spins with `pause`; if the stream is backed up behind earlier work for long (or several ranks
+// share the host's cores) it hands its time slice back between looks instead of burning a core per rank.  Falls back to a
+// real synchronise after ~2 s (surfacing any GPU error).
 // The wait is typically as long as the previous backward (the host runs one step ahead: 0.25 ms at the bench size), so the
 // calling thread spins through it; it starts yielding its core only after a millisecond.  (Yielding after 100 us, as until
 // round 3, put every steady-state wait into sched_yield: on a box with busy neighbours the thread can lose its core for a
@@ -721,8 +720,8 @@ int gs2d_forward_batch(int K, const gs2d_frame_io* io, int P, int D, int M, cons
     }
     auto drain = [&]() { for (int k = 0; k < K; k++) (void)wait_total(f[k], c.s); };
     if (img_layout(width, height).tiles <= GS2D_BIN_MAX_TILES) {
-        // every stage as ONE launch over the K frames (blockIdx.y = frame): 8 launches instead of 7 K + 1, and the
-        // latency-bound stages (block-sum scan, tile histogram, row scan, scatter, per-tile depth sort) get K times the
+        // every stage as ONE launch over the K frames (blockIdx.y = frame): 7 launches instead of 6 K + 1, and the
+        // latency-bound stages (duplicate, tile histogram, row scan, scatter, per-tile depth sort) get K times the
         // workgroups for the same latency
         if (fwd_batch_fused(c, f, K) < 0) { drain(); return -1; }
     } else {
