@@ -527,11 +527,24 @@ def slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world):
         step_desc = "render + fused mapping loss (value + gradients in one call) + backward (gradients written into the bucket) + fused Adam over the SoA"
         metric = f"mapping iterations/sec @ {W}x{H}, {P // 1000}k Gaussians"
     elapsed = timed(one_step, args.steps, args.warmup, world, dev)
+    # per-stage device time of the operator's kernels inside the iteration (hipEvents on the launch stream; separate, untimed leg)
+    L = _lib.lib()
+    L.gs2d_stage_timing_enable(1)
+    acc = [0.0] * len(STAGES)
+    buf = (C.c_float * len(STAGES))()
+    for _ in range(10):
+        one_step()
+        L.gs2d_stage_timing_read(buf)
+        for i in range(len(STAGES)):
+            acc[i] += max(buf[i], 0.0)
+    L.gs2d_stage_timing_enable(0)
+    stage_ms = {n: round(acc[i] / 10, 4) for i, n in enumerate(STAGES)}
     return {"metric": metric, "value": round(args.steps / elapsed, 3), "unit": "iterations/s", "n_gpus": 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {W}x{H} / {P} Gaussians, {args.workload} iteration (BASELINE.json configs[2] loop shape), "
-                                   f"use_sa={use_sa}", "step": step_desc, "parallelism": "single GPU", "prewarm_steps": PREWARM_DONE},
+                                   f"use_sa={use_sa}", "step": step_desc, "parallelism": "single GPU", "prewarm_steps": PREWARM_DONE,
+                       "stage_ms": stage_ms},
             "roofline": None, "cpu_baseline": None}
 
 

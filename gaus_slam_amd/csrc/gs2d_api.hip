@@ -802,6 +802,12 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         }
     }
     const bool det = known ? fr.det != 0 : false;
+    // Pose-only fast path (tracking with every Gaussian parameter detached): both stages in this call, no per-Gaussian output
+    // of any kind, non-deterministic mode.  The blend stage then accumulates only the three dL_dT components dL/dmean needs, in
+    // a dense layout over the head of the gradient records, and a 40-B-per-Gaussian kernel reduces the pose gradient from them.
+    const bool pose_fast = (stages & 3) == 3 && pose_Rt != nullptr && dL_dmean3D == nullptr && dL_dtransMat == nullptr &&
+                           dL_dnormal == nullptr && dL_dsh == nullptr && shs == nullptr && scales != nullptr &&
+                           rotations != nullptr && !det && !live_det;
     if (dL_dpose != nullptr && (stages & 1) != 0 && (R <= 0 || det))
         GS2D_CHECK(hipMemsetAsync(dL_dpose, 0, sizeof(float) * pose_floats, s), "memset dL_dpose");
     const GeomLayout GL = geom_layout(P);
@@ -822,7 +828,8 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
             GS2D_CHECK(hipMemsetAsync(grad_rec, 0, sizeof(float) * GS2D_GRAD_FLOATS * (size_t)P, s), "memset grad_rec");
         if (R > 0) {
             g_timer.begin(ST_BLEND_BWD, s);
-            const gs2d::BlendBwdFrame bf = {ranges, point_list, rec, pix_state, hits, dL_dpix, dL_depths, grad_rec, nullptr};
+            const gs2d::BlendBwdFrame bf = {ranges, point_list, rec, pix_state, hits, dL_dpix, dL_depths, grad_rec, nullptr,
+                                            pose_fast ? grad_rec + 4 * (size_t)P : nullptr};
             gs2d::launch_blend_bwd(width, height, 1, &bf, background, use_sa, dL_dpose, pose_floats, s);
             g_timer.end(ST_BLEND_BWD, s);
             GS2D_STAGE("blend_bwd");
@@ -836,7 +843,7 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         g_timer.begin(ST_BLEND_BWD, s);
         if (R > 0) {
             GS2D_CHECK(hipMemsetAsync(det_slots, 0, sizeof(float) * GS2D_GRAD_FLOATS * 4 * (size_t)R, s), "memset det_slots");
-            const gs2d::BlendBwdFrame bf = {ranges, point_list, rec, pix_state, hits, dL_dpix, dL_depths, grad_rec, det_slots};
+            const gs2d::BlendBwdFrame bf = {ranges, point_list, rec, pix_state, hits, dL_dpix, dL_depths, grad_rec, det_slots, nullptr};
             gs2d::launch_blend_bwd(width, height, 1, &bf, background, use_sa, nullptr, 0, s);
         }
         gs2d::launch_det_reduce(P, R, width, height, ranges, point_list, (const ushort4*)(geom_buffer + GL.rect),
@@ -857,6 +864,10 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         cam.gy = (height + GS2D_TILE - 1) / GS2D_TILE;
         cam.tight = 0;
         g_timer.begin(ST_PREPROCESS_BWD, s);
+        if (pose_fast)
+            gs2d::launch_preprocess_bwd_pose(P, means3D, radii, scales, rotations, cam, grad_rec, grad_rec + 4 * (size_t)P, pose_Rt,
+                                             pose_quat, dL_dpose, s);
+        else
         gs2d::launch_preprocess_bwd(g_begin, g_end, D, M, means3D, rec, radii, shs, clamped, scales, rotations, cam, grad_rec,
                                     dL_dtransMat, dL_dnormal, dL_dcolor, dL_dopacity, dL_dsh, dL_dmean2D, dL_dmean3D,
                                     dL_dscale, dL_drot, pose_Rt, pose_quat, pose_Rt ? dL_dpose : nullptr,
@@ -909,7 +920,7 @@ int gs2d_backward_batch(int K, const gs2d_frame_grad* fr, int accumulate, int P,
             b.rec = (const float4*)(f.geom_buffer + GL.rec);
             b.pix_state = (const float*)(f.img_buffer + IL.pix);
             b.hits = (const uint8_t*)(f.binning_buffer + BL.hits4);
-            b.dL_dpix = f.dL_dpix; b.dL_dothers = f.dL_depths; b.grad_rec = grad_rec; b.det_slots = nullptr;
+            b.dL_dpix = f.dL_dpix; b.dL_dothers = f.dL_depths; b.grad_rec = grad_rec; b.det_slots = nullptr; b.dense_m2d = nullptr;
         }
     }
     if (nb > 0) {

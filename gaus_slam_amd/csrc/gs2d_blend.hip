@@ -566,6 +566,27 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
     return v;
 }
 
+// --- 3-value reduction inside ONE 16-lane DPP row (pose-only backward): the same mirror / half-mirror levels with bank-masked
+// overwrites, then two full quad levels: 7 DPP adds.  Every lane of quad 0 (lanes 0-3) of a row ends with the row's total of
+// v0, quad 2 (lanes 8-11) with that of v1, quad 1 (lanes 4-7) with that of v2; lanes 12-15 hold nothing of use.
+__device__ __forceinline__ float reduce3_row(float v0, float v1, float v2)
+{
+    float e0, e1, f0;
+    // (s_nop: VALU write -> DPP read of the same register needs 2 wait states and the compiler does not look inside asm blocks;
+    // e0's last write is followed by the write of e1 and one s_nop 0 before the half-mirror level reads it)
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %2, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa"
+        : "=&v"(e0), "=&v"(e1), "=&v"(f0)
+        : "v"(v0), "v"(v1), "v"(v2));
+    const float g = f0 + dpp_get<0x4E>(f0);  // quad_perm [2,3,0,1]
+    return g + dpp_get<0xB1>(g);             // quad_perm [1,0,3,2]
+}
+
 // Gradient record (GS2D_GRAD_FLOATS = 20 floats per Gaussian):
 //   [0..2] dL_dcolor  [3..5] dL_dnormal  [6..14] dL_dT (Tu,Tv,Tw)  [15] dL_dopacity  [16,17] dL_dmean2D.xy
 //
@@ -630,6 +651,7 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
 #endif
 #define GS2D_ACC 13
 #define GS2D_ACC_DET 18
+#define GS2D_ACC_POSE 3   // pose-only backward: dT[2], dT[5], dT[8] -- all dL/dmean needs (gs2d_preprocess.hip, backward.cu:637-663)
 template <int NACC>
 struct BwdBatchT {
     // Entries past a queue's end hold slot 63 -- the deepest staged splat, always a real record -- and a row is live while the
@@ -647,14 +669,22 @@ struct BwdBatchT {
     uint32_t tail[4];   // the pipeline reads up to two entries past a full queue (values unused)
 };
 
-template <bool USE_SA, bool DET, bool BATCH>
+// POSE (tracking with every Gaussian parameter detached, render/__init__.py:31-36; chosen by gs2d_backward_staged when all six
+// per-Gaussian outputs are NULL): the pose gradient needs dL/dmean = Pm^T (dT[2], dT[5], dT[8]) only (backward.cu:637-663; plus
+// the rare low-pass dL_dmean2D pair, which feeds those three through the centre formula), so the trip forms only -dk.z, -dl.z and
+// the Tw.z component (no dp2, no colour / opacity / x,y terms: the atomics of backward.cu:343,396,441-449,460 that tracking
+// throws away), reduces them with the 3-value row reduction, keeps 3 accumulators per staged splat and flushes them into a
+// DENSE float4-per-Gaussian array laid over the head of the (forward-cleared) gradient records; dL_dmean2D goes to
+// dense_m2d[2 g].  Single frame, non-deterministic mode only.
+template <bool USE_SA, bool DET, bool BATCH, bool POSE = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DET ? 4 : GS2D_WAVES_PER_EU, DET ? 4 : GS2D_WAVES_PER_EU)))
 blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const float* __restrict__ bg, size_t plane,
                  float* __restrict__ clear12, int clear_n,
                  const std::conditional_t<BATCH, gs2d::BlendBwdBatch, gs2d::BlendBwdFrame> args)
 {
     if (clear12 != nullptr && blockIdx.x == 0 && (int)threadIdx.x < clear_n) clear12[threadIdx.x] = 0.f;
-    constexpr int NACC = DET ? GS2D_ACC_DET : GS2D_ACC;
+    static_assert(!(POSE && (DET || BATCH)), "the pose-only backward is single-frame and non-deterministic");
+    constexpr int NACC = DET ? GS2D_ACC_DET : (POSE ? GS2D_ACC_POSE : GS2D_ACC);
     typedef BwdBatchT<NACC> BwdBatch;
     __shared__ BwdBatch batches[4];
     int local_block = blockIdx.x;
@@ -675,6 +705,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     const float* __restrict__ dL_dothers = fa->dL_dothers;
     float* __restrict__ grad_rec = fa->grad_rec;
     float* __restrict__ det_slots = fa->det_slots;
+    float* __restrict__ dense_m2d = fa->dense_m2d;
     const int tile = xcd_tile(local_block, ntiles);
     if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
@@ -757,7 +788,9 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     // 0-2 colour | 3-8 Tu,Tv (-dk, -dl) | 9-11 Tw | 12-14 normal | 15 opacity
     const int slot = reduce16_row_index(lane);
     // LDS accumulator of this lane's slot; -1: normal component, added straight to the global record (not in DET: 13..15)
-    const int acc_comp = slot < 12 ? slot : (slot == 15 ? 12 : (DET ? slot + 1 : -1));
+    // (POSE: reduce3_row leaves the totals of -dk.z / -dl.z / Tw.z in quads 0 / 2 / 1 of the row; one lane of each adds them up)
+    const int acc_comp = POSE ? (li == 0 ? 0 : (li == 8 ? 1 : (li == 4 ? 2 : -1)))
+                              : (slot < 12 ? slot : (slot == 15 ? 12 : (DET ? slot + 1 : -1)));
 #pragma unroll
     for (int i = 0; i < NACC; i++) wb.acc()[i * 64 + lane] = 0.f;
     if (lane < 4) wb.tail[lane] = 0x3F3F3F3Fu;
@@ -954,11 +987,20 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                 const float d_gG = ray ? d_x : 0.f, d_t = ray ? 0.f : d_x * GS2D_FILTER_INV_SQ;                       \
                 const float d_zr = ray ? d_z : 0.f, d_zl = ray ? 0.f : d_z;                                           \
                 if (GS2D_BWD_SKIP2(am != 0ull)) {                                                                      \
-                    float g[16];                                                                                      \
-                    g[0] = d_w * dpx0; g[1] = d_w * dpx1; g[2] = d_w * dpx2;                                          \
                     const float dL_ds0 = fmaf(d_gG, s0, d_zr * G2.x);                                                 \
                     const float dL_ds1 = fmaf(d_gG, s1, d_zr * G2.y);                                                 \
                     const float dsx = dL_ds0 * ip, dsy = dL_ds1 * ip;                                                 \
+                    float tot;                                                                                        \
+                    if (POSE) { /* the z components only: the same expressions as g[5], g[8], g[11] below */          \
+                        const float nk2 = fmaf(l1, dsx, -(l0 * dsy));                                                 \
+                        const float nl2 = fmaf(dsy, k0, -(dsx * k1));                                                 \
+                        tot = reduce3_row(nk2, nl2, fmaf(-pxf, nk2, fmaf(-pyf, nl2, d_zr)) + d_zl);                   \
+                        if (acc_comp >= 0) {                                                                          \
+                            GS2D_BWD_LDS_ACCUM(J, tot)                                                                \
+                        }                                                                                             \
+                    } else {                                                                                          \
+                    float g[16];                                                                                      \
+                    g[0] = d_w * dpx0; g[1] = d_w * dpx1; g[2] = d_w * dpx2;                                          \
                     const float dp2 = -fmaf(dsx, s0, dsy * s1);                                                       \
                     /* the record holds -dk, -dl: formed directly (operands of the cross products swapped; the sign of  \
                        the Tw terms rides on the FMAs' source modifiers) -- exact, and no sign flip after the reduction */ \
@@ -971,7 +1013,6 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                     g[11] = fmaf(-pxf, nk2, fmaf(-pyf, nl2, d_zr)) + d_zl;                                            \
                     g[15] = d_op;                                                                                     \
                     /* each row reduces ITS splat into the splat's LDS accumulators */                                \
-                    float tot;                                                                                        \
                     GS2D_EXP_BUTTERFLY                                                                                \
                     if (ANY_DN) {                                                                                     \
                         g[12] = d_w * dn0; g[13] = d_w * dn1; g[14] = d_w * dn2;                                      \
@@ -988,6 +1029,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                         GS2D_BWD_LDS_ACCUM(J, tot)                                                                    \
                     } else if (ANY_DN && tot != 0.f)                                                                  \
                         atomicAdd(grad_rec + (size_t)(wb.pn[J] & 0x0FFFFFFFu) * GS2D_GRAD_FLOATS + (slot - 9), tot); \
+                    }                                                                                                 \
                     if (ballot64(d_t != 0.f) != 0) {                                                                  \
                         const float g_mx = row_sum_to_lane15(d_t * d0);                                               \
                         const float g_my = row_sum_to_lane15(d_t * d1);                                               \
@@ -997,8 +1039,9 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                                     wb.acc()[J * NACC + 16] += g_mx; wb.acc()[J * NACC + 17] += g_my;                   \
                                 }                                                                                     \
                         } else if (li == 15 && (g_mx != 0.f || g_my != 0.f)) {                                        \
-                            float* dst = grad_rec + (size_t)(wb.pn[J] & 0x0FFFFFFFu) * GS2D_GRAD_FLOATS;         \
-                            atomicAdd(dst + 16, g_mx); atomicAdd(dst + 17, g_my);                                     \
+                            float* dst = POSE ? dense_m2d + (size_t)(wb.pn[J] & 0x0FFFFFFFu) * 2                      \
+                                              : grad_rec + (size_t)(wb.pn[J] & 0x0FFFFFFFu) * GS2D_GRAD_FLOATS + 16;  \
+                            atomicAdd(dst, g_mx); atomicAdd(dst + 1, g_my);                                           \
                         }                                                                                             \
                     }                                                                                                 \
                 }                                                                                                     \
@@ -1025,6 +1068,19 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                         const int off = c < 3 ? c : (c < 12 ? c + 3 : (c == 12 ? 15 : (c < 16 ? c - 10 : c)));
                         dst[off] = wb.acc()[fa * NACC + c];
                         wb.acc()[fa * NACC + c] = 0.f;
+                    }
+                }
+            }
+        } else if (POSE) {
+            // sixteen splats per pass: lane l flushes accumulator (l & 3) of slot f0 + l / 4 into the dense float4 of its Gaussian
+            for (int f0 = 64 - fill; f0 < 64; f0 += 16) {
+                const int fs = f0 + (lane >> 2), c = lane & 3;
+                if (fs < 64 && c < GS2D_ACC_POSE) {
+                    float* pa = &wb.acc()[fs * GS2D_ACC_POSE + c];
+                    const float va = *pa;
+                    if (va != 0.f) {
+                        *pa = 0.f;
+                        atomicAdd(grad_rec + (size_t)(wb.pn[fs] & 0x0FFFFFFFu) * 4 + c, va);
                     }
                 }
             }
@@ -1092,6 +1148,15 @@ void launch_blend_bwd(int W, int H, int K, const BlendBwdFrame* frames, const fl
     const size_t plane = (size_t)gx * gy * GS2D_TILE_PIX;
     const int bpf = GS2D_XCDS * ((gx * gy + GS2D_XCDS - 1) / GS2D_XCDS);
     const bool det = frames[0].det_slots != nullptr;
+    if (K == 1 && !det && frames[0].dense_m2d != nullptr) {  // pose-only instantiation
+        if (use_sa)
+            hipLaunchKernelGGL((blend_bwd_kernel<true, false, false, true>), dim3(bpf), dim3(256), 0, s, W, H, gx, gx * gy, bpf, bg,
+                               plane, clear12, clear_n, frames[0]);
+        else
+            hipLaunchKernelGGL((blend_bwd_kernel<false, false, false, true>), dim3(bpf), dim3(256), 0, s, W, H, gx, gx * gy, bpf, bg,
+                               plane, clear12, clear_n, frames[0]);
+        return;
+    }
 #define GS2D_LAUNCH_BWD(SA, DET, BATCH, GRID, ARGS)                                                                       \
     hipLaunchKernelGGL((blend_bwd_kernel<SA, DET, BATCH>), dim3(GRID), dim3(256), 0, s, W, H, gx, gx * gy, bpf, bg, plane,  \
                        clear12, clear_n, ARGS)

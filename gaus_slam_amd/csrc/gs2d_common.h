@@ -196,6 +196,10 @@ void launch_preprocess_bwd(int first, int P, int D, int M, const float* means3D,
                            float* dL_dcolor, float* dL_dopacity, float* dL_dsh, float* dL_dmean2D,
                            float* dL_dmean3D, float* dL_dscale, float* dL_drot, const float* pose_Rt, const float* pose_q,
                            float* dL_dpose, int need_record, float* pose_partials, hipStream_t s);
+// pose-only per-Gaussian stage: reads the dense sums the POSE instantiation of blend_bwd left (BlendBwdFrame::dense_m2d)
+void launch_preprocess_bwd_pose(int P, const float* means3D, const int* radii, const float* scales, const float* rotations,
+                                const CamParams& cam, const float* dense_T, const float* dense_m2d, const float* pose_Rt,
+                                const float* pose_q, float* dL_dpose, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
 void launch_pose_quat(const float* pose_Rt, float* q_out, hipStream_t s);
 // inclusive scan of n u32; tmp must hold ceil(n/1024)+64 u32. If total_out != nullptr the grand total is stored there.
@@ -288,6 +292,8 @@ struct BlendBwdFrame {
     const float* dL_dpix; const float* dL_dothers; float* grad_rec;
     float* det_slots;  // != nullptr selects the deterministic variant (single frame only): no atomics, per-(instance, quadrant)
                        // partial records (GS2D_GRAD_FLOATS floats each, R * 4 of them, zero-initialised by the caller)
+    float* dense_m2d;  // != nullptr selects the POSE-ONLY variant (single frame, non-deterministic): grad_rec is then used as a
+                       // dense float4[P] (dT[2], dT[5], dT[8], -) and dense_m2d as float2[P] dL_dmean2D.xy (both zero on entry)
 };
 struct BlendBwdBatch { BlendBwdFrame f[GS2D_MAX_BATCH]; };
 // Writes hits (u16[4 * i + q] = the 2x2 pixel groups of quadrant q that instance i of the sorted list can touch, see

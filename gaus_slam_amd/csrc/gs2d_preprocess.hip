@@ -641,6 +641,75 @@ preprocess_bwd_kernel(int first, int P, int D, int M, const float* __restrict__ 
     }
 }
 
+// Pose-only per-Gaussian stage (tracking with every Gaussian parameter detached, render/__init__.py:31-36): the blend stage
+// ran in its POSE instantiation and left, densely, dense_T[g] = (dT[2], dT[5], dT[8], -) and dense_m2d[g] = dL_dmean2D.xy.
+// dL/dmean = row 2 of dL_dM = Pm dL_dT^T (backward.cu:583-590, 637-663) needs nothing else -- no rotation, no scale, no
+// transform -- unless the rare low-pass pair is non-zero, whose centre-formula terms (backward.cu:538-563) need T.
+// Same expression order as preprocess_bwd_one, so both paths produce the same per-Gaussian dmean bit for bit.
+// 40 B per visible Gaussian instead of ~150.
+__global__ void __launch_bounds__(256)
+preprocess_bwd_pose_kernel(int P, const float* __restrict__ means3D, const int* __restrict__ radii,
+                           const float* __restrict__ scales, const float* __restrict__ rotations, const CamParams cam,
+                           const float4* __restrict__ dense_T, const float2* __restrict__ dense_m2d,
+                           const float* __restrict__ pose_Rt, const float* __restrict__ pose_q, float* __restrict__ dL_dpose)
+{
+    const float* pm = cam.pm;
+    const float halfW = (float)cam.W * 0.5f, halfWm = (float)(cam.W - 1) * 0.5f;
+    const float halfH = (float)cam.H * 0.5f, halfHm = (float)(cam.H - 1) * 0.5f;
+    float Pm[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        Pm[a][0] = pm[4 * a] * halfW + pm[4 * a + 3] * halfWm;
+        Pm[a][1] = pm[4 * a + 1] * halfH + pm[4 * a + 3] * halfHm;
+        Pm[a][2] = pm[4 * a + 3];
+    }
+    float pg[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) pg[i] = 0.f;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < P; idx += gridDim.x * 256) {
+        if (!(radii[idx] > 0)) continue;
+        const float4 gT = dense_T[idx];
+        const float2 gm = dense_m2d[idx];
+        float d2 = gT.x, d5 = gT.y, d8 = gT.z;
+        const float wx = means3D[3 * idx], wy = means3D[3 * idx + 1], wz = means3D[3 * idx + 2];
+        if (gm.x != 0 || gm.y != 0) {  // backward.cu:538-563 (rare: a pixel took the low-pass branch of this splat)
+            float px = wx, py = wy, pz = wz;
+            pose_point(pose_Rt, px, py, pz);
+            float qcam[4], qsign, w, x, y, z, T[9], normal[3];
+            load_pose_quat(pose_Rt, pose_q, qcam);
+            const float4 q = pose_quat(qcam, reinterpret_cast<const float4*>(rotations)[idx], qsign);
+            const float2 sc = reinterpret_cast<const float2*>(scales)[idx];
+            const Mat3 R = quat_to_R(q, w, x, y, z);
+            compute_transmat(px, py, pz, sc.x, sc.y, R, pm, cam.vm, cam.W, cam.H, T, normal);
+            const float distance = T[6] * T[6] + T[7] * T[7] - T[8] * T[8];
+            const float f = 1 / distance;
+            d2 += gm.x * (-f * T[8]);
+            d5 += gm.y * (-f * T[8]);
+            d8 += gm.x * (-T[2] * (f + 2 * f * f * T[8] * T[8])) + gm.y * (-T[5] * (f + 2 * f * f * T[8] * T[8]));
+        }
+        const float g0 = (Pm[0][0] * d2 + Pm[0][1] * d5) + Pm[0][2] * d8;
+        const float g1 = (Pm[1][0] * d2 + Pm[1][1] * d5) + Pm[1][2] * d8;
+        const float g2 = (Pm[2][0] * d2 + Pm[2][1] * d5) + Pm[2][2] * d8;
+        pg[0] += g0 * wx; pg[1] += g0 * wy; pg[2] += g0 * wz; pg[3] += g0;
+        pg[4] += g1 * wx; pg[5] += g1 * wy; pg[6] += g1 * wz; pg[7] += g1;
+        pg[8] += g2 * wx; pg[9] += g2 * wy; pg[10] += g2 * wz; pg[11] += g2;
+    }
+    __shared__ float red[4][12];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        float v = pg[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (v != 0.f) atomicAdd(dL_dpose + threadIdx.x, v);
+    }
+}
+
 // Batched form (gs2d_backward_batch): blockIdx.y = frame.  No pose, no deterministic variant.
 __global__ void __launch_bounds__(256)
 preprocess_bwd_batch_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
@@ -781,6 +850,19 @@ void launch_preprocess_bwd(int first, int P, int D, int M, const float* means3D,
                        dL_dpose != nullptr ? pose_partials : nullptr);
     if (dL_dpose != nullptr && pose_partials != nullptr)
         hipLaunchKernelGGL(pose_reduce_kernel, dim3(1), dim3(64), 0, s, grid, pose_partials, dL_dpose);
+}
+
+void launch_preprocess_bwd_pose(int P, const float* means3D, const int* radii, const float* scales, const float* rotations,
+                                const CamParams& cam, const float* dense_T, const float* dense_m2d, const float* pose_Rt,
+                                const float* pose_q, float* dL_dpose, hipStream_t s)
+{
+    if (P <= 0) return;
+    // a streaming kernel of 40 B per Gaussian: enough workgroups to fill the chip, few enough that the 12 atomics each of them
+    // ends with do not queue up on the pose-gradient words
+    int grid = (P + 255) / 256;
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(preprocess_bwd_pose_kernel, dim3(grid), dim3(256), 0, s, P, means3D, radii, scales, rotations, cam,
+                       reinterpret_cast<const float4*>(dense_T), reinterpret_cast<const float2*>(dense_m2d), pose_Rt, pose_q, dL_dpose);
 }
 
 void launch_pose_quat(const float* pose_Rt, float* q_out, hipStream_t s)

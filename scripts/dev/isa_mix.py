@@ -69,8 +69,9 @@ def main():
                               stderr=subprocess.DEVNULL)
         src = open(out).read()
     print(f"# ISA instruction mix of {os.path.relpath(SRC, ROOT)} (hipcc {' '.join(FLAGS)})")
-    for kname, title in (("blend_fwd_kernelILb1E", "blend_fwd_kernel<USE_SA=true>"),
-                         ("blend_bwd_kernelILb1ELb0E", "blend_bwd_kernel<USE_SA=true, DET=false>")):
+    for kname, title in (("blend_fwd_kernelILb1ELb0E", "blend_fwd_kernel<USE_SA=true, BATCH=false>"),
+                         ("blend_bwd_kernelILb1ELb0ELb0ELb0E", "blend_bwd_kernel<USE_SA=true, DET=false, BATCH=false, POSE=false>"),
+                         ("blend_bwd_kernelILb1ELb0ELb0ELb1E", "blend_bwd_kernel<USE_SA=true, DET=false, BATCH=false, POSE=true> (tracking)")):
         m = re.search(r"\n(_ZN\S*" + kname + r"\S*):[^\n]*\n(.*?)s_endpgm", src, re.S)
         body = m.group(2)
         ops, labels = [], {}
@@ -85,8 +86,13 @@ def main():
                 parts = t.split()
                 ops.append((parts[0], parts[-1] if len(parts) > 1 else ""))
         names = [o for o, _ in ops]
-        vg = re.search(r"\.vgpr_count:\s+(\d+)", src[m.end():m.end() + 6000])
-        print(f"\n{title}: {len(ops)} instructions in the kernel" + (f", {vg.group(1)} VGPRs" if vg else ""))
+        meta = [e for e in src.split("\n  - .a") if re.search(r"\.name:\s+" + re.escape(m.group(1)) + r"\n", e)]
+        info = ""
+        if meta:
+            f = lambda k: (re.search(r"\." + k + r":\s+(\d+)", meta[0]) or [None, "?"])[1]
+            info = (f", {f('vgpr_count')} VGPRs, {f('vgpr_spill_count')} spilled, scratch {f('private_segment_fixed_size')} B, "
+                    f"LDS {f('group_segment_fixed_size')} B")
+        print(f"\n{title}: {len(ops)} instructions in the kernel{info}")
         q = [i for i, o in enumerate(names) if o == "ds_read_u8"]
         # the body without normal-channel gradients comes last in the backward; the forward has one body.  Each body has
         # two prologue queue reads and one per unrolled step: step A = [read A, read B), step B = [read B, back edge]

@@ -201,3 +201,67 @@ def test_pose_quaternion_derived_in_the_kernels_equals_the_passed_one():
         assert outs[0][0] == outs[1][0] > 0
         for a, b in zip(outs[0][1:], outs[1][1:]):
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_sa", [True, False])
+def test_pose_only_backward_matches_the_oracle_and_the_generic_path(oracle, use_sa):
+    """Tracking detaches every Gaussian parameter (render/__init__.py:31-36): gs2d_backward_staged with all six per-Gaussian
+    outputs NULL runs the POSE instantiation of blend_bwd_kernel (only dT[2], dT[5], dT[8] and the rare low-pass pair are formed,
+    reduced and flushed, into a dense layout) and a 40-B-per-Gaussian reduction kernel.  Its dL/d[R|t] has to equal the oracle's
+    (<= 1e-4 of the tensor's maximum, every entry) and the generic path's.  A tenth of the splats is made thinner than the
+    low-pass disc so that the dL_dmean2D / centre-formula route (backward.cu:450-457, 538-563) carries gradient too; upstream
+    gradients on colour and on allmap channels 0, 1, 5, 6."""
+    from gaus_slam_amd import rasterizer
+    from gaus_slam_amd.tracking import matrix_to_quaternion
+    W, H, P = 320, 240, 6000
+    sc, w2c = _world_scene(P, W, H, seed=31)
+    sc["scales"] = sc["scales"].clone()
+    sc["scales"][::10] *= 0.02  # sigma << 0.1 px: those splats are seen through the low-pass filter only
+    cam = sc["cam"]
+    Rt = w2c[:3, :4].contiguous()
+    qc = matrix_to_quaternion(w2c[:3, :3]).contiguous()
+    o = oracle.forward_posed(sc["means3D"].numpy(), sc["rotations"].numpy(), Rt.numpy(), qc.numpy(), sc["opacities"].numpy(),
+                             cam.viewmatrix.numpy(), cam.projmatrix.numpy(), cam.campos.numpy(), W, H, cam.tanfovx,
+                             cam.tanfovy, scales=sc["scales"].numpy(), colors_precomp=sc["colors"].numpy(), use_sa=use_sa)
+    dev = torch.device("cuda")
+    e = torch.empty(0, device=dev)
+    t = lambda a: a.to(dev).contiguous()
+    args = (torch.tensor([0.1, 0.2, 0.3], device=dev), t(sc["means3D"]), t(sc["colors"]), t(sc["opacities"]), t(sc["scales"]),
+            t(sc["rotations"]), 1.0, e, t(cam.viewmatrix), t(cam.projmatrix), cam.tanfovx, cam.tanfovy, H, W, e, 0,
+            t(cam.campos), use_sa, False, False)
+    o["bg"] = np.array([0.1, 0.2, 0.3], np.float32)  # (the background only enters the backward: same forward lists and state)
+    stable = (o["stability"] > 2e-5).reshape(H, W)
+    dc, da = util.make_upstream_grads(W, H, channels=(0, 1, 5, 6))
+    dc, da = (dc * W * H).numpy(), (da * W * H).numpy()
+    dc[:, ~stable] = 0; da[:, ~stable] = 0
+    go = oracle.backward_posed(o, dc, da)
+    assert np.abs(go["dL_dmeans2D_blend"]).max() > 0, "the scene is meant to exercise the low-pass branch"
+    dct, dat = torch.from_numpy(dc).to(dev), torch.from_numpy(da).to(dev)
+
+    def bwd(**kw):
+        R, color, allmap, radii, geom, binning, img = rasterizer.rasterize_gaussians(*args, pose_Rt=t(Rt), pose_quat=t(qc))
+        return rasterizer.rasterize_gaussians_backward(
+            args[0], args[1], radii, args[2], args[4], args[5], 1.0, e, args[8], args[9], args[10], args[11], dct, dat, e, 0,
+            args[16], geom, R, binning, img, use_sa, False, pose_Rt=t(Rt), pose_quat=t(qc), **kw)
+
+    out = torch.full((4, 4), float("nan"), device=dev)  # uninitialised memory is allowed: all sixteen words are written
+    fast = bwd(pose_only_out=out).cpu().numpy()
+    assert np.all(fast[3] == 0)
+    generic = bwd()[8].cpu().numpy()
+    ref = go["dL_dpose"]
+    scale = np.abs(ref).max()
+    print(f"pose-only vs oracle {np.abs(fast[:3] - ref).max() / scale:.2e}, generic vs oracle {np.abs(generic - ref).max() / scale:.2e}, "
+          f"pose-only vs generic {np.abs(fast[:3] - generic).max() / scale:.2e}")
+    assert np.abs(fast[:3] - ref).max() <= 1e-4 * scale
+    assert np.abs(fast[:3] - generic).max() <= 2e-5 * scale  # the same per-Gaussian values, summed in another order
+    # a second pose-only backward on the SAME forward (the accumulator is no longer clean: cleared by a memset) gives the same
+    R, color, allmap, radii, geom, binning, img = rasterizer.rasterize_gaussians(*args, pose_Rt=t(Rt), pose_quat=t(qc))
+    two = []
+    for _ in range(2):
+        out2 = torch.empty((4, 4), device=dev)
+        rasterizer.rasterize_gaussians_backward(
+            args[0], args[1], radii, args[2], args[4], args[5], 1.0, e, args[8], args[9], args[10], args[11], dct, dat, e, 0,
+            args[16], geom, R, binning, img, use_sa, False, pose_Rt=t(Rt), pose_quat=t(qc), pose_only_out=out2)
+        two.append(out2.cpu().numpy())
+    assert np.abs(two[0] - two[1]).max() <= 2e-5 * scale
