@@ -556,8 +556,22 @@ int orc_blend_fwd_pixel(int W, int H, int px, int py, const uint32_t* ranges, co
  * [6..14] dL_dtransMat (Tu,Tv,Tw), [15..16] dL_dmean2D.xy, [17] dL_dopacity.
  */
 #define ACC_STRIDE 20
+/* orc_set_float_accumulation(1): the per-Gaussian sums of orc_blend_bwd are accumulated in FLOAT32, one add per (pixel,
+ * splat) contribution -- what the reference's atomicAdd(float) does (backward.cu:343,396,441-460; its order is whatever the
+ * hardware makes it, here it is the thread schedule's).  Default 0: double accumulation (see the header).  Used by the
+ * rounding-error tests to tell the error of float32 ACCUMULATION, which the reference has too, from the error of the
+ * per-pair arithmetic. */
+static int orc_float_acc = 0;
+static float* orc_accf = NULL;
+void orc_set_float_accumulation(int on) { orc_float_acc = on != 0; }
 static void acc_add(double* acc, size_t g, int k, double v)
 {
+    if (orc_accf) {
+        const float vf = (float)v;
+#pragma omp atomic
+        orc_accf[g * ACC_STRIDE + k] += vf;
+        return;
+    }
 #pragma omp atomic
     acc[g * ACC_STRIDE + k] += v;
 }
@@ -574,6 +588,7 @@ void orc_blend_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t* 
     const size_t HW = (size_t)H * W;
     double* acc = (double*)calloc((size_t)P * ACC_STRIDE + 1, sizeof(double));
     if (extra_acc) memcpy(acc, extra_acc, (size_t)P * ACC_STRIDE * sizeof(double));
+    orc_accf = orc_float_acc ? (float*)calloc((size_t)P * ACC_STRIDE + 1, sizeof(float)) : NULL;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gx * gy; tile++) {
         const int tx = tile % gx, ty = tile / gx;
@@ -713,6 +728,11 @@ void orc_blend_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t* 
                     acc_add(acc, g, 17, (double)(G * dL_dalpha));
                 }
             }
+    }
+    if (orc_accf) {
+        for (size_t i = 0; i < (size_t)P * ACC_STRIDE; i++) acc[i] += (double)orc_accf[i];
+        free(orc_accf);
+        orc_accf = NULL;
     }
     for (size_t g = 0; g < (size_t)P; g++) {
         const double* a = acc + g * ACC_STRIDE;

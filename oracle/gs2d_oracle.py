@@ -24,8 +24,8 @@ TILE = 16
 
 def build(force=False):
     """Compile the C oracle with gcc (oracle/Makefile)."""
-    src = os.path.join(_HERE, "gs2d_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("gs2d_oracle.c", "gs2d_oracle_f64.c", "gs2d_oracle_forms.c", "Makefile")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libgs2d_oracle.so"])
     return _LIB_PATH
 
@@ -53,6 +53,11 @@ def _f32(a):
 
 def higher_msb(n):
     return int(lib().orc_higher_msb(C.c_uint32(n)))
+
+
+def set_float_accumulation(on):
+    """orc_set_float_accumulation: per-Gaussian gradient sums in float32 (the reference's float atomics) instead of double."""
+    lib().orc_set_float_accumulation(C.c_int(int(bool(on))))
 
 
 def set_threads(n):
@@ -199,12 +204,17 @@ def pixel_variants(st, px, py, knife, max_decisions=6):
     return nk, out
 
 
-def backward(st, dL_dcolor, dL_dallmap, pixel_overrides=None, knife=0.0):
+FORM_EXP2, FORM_RCP, FORM_MERGED, FORM_CLOSED, FORM_CONF, FORM_EXPAND = 1, 2, 4, 8, 16, 32  # gs2d_oracle_forms.c
+
+
+def backward(st, dL_dcolor, dL_dallmap, pixel_overrides=None, knife=0.0, forms=None):
     """Backward for a forward() state.  Returns the 8 gradients of
     RAST/rasterize_points.cu:238 (+ the internal dL_dnormal).
     pixel_overrides (optional): list of (px, py, flipmask) -- those pixels take part under the given outcome of their
     near-threshold decisions (the numbering of pixel_variants, same `knife`) instead of the oracle's own outcome: their
-    upstream gradient is removed from the plain pass and their contribution comes from orc_blend_bwd_pixel."""
+    upstream gradient is removed from the plain pass and their contribution comes from orc_blend_bwd_pixel.
+    forms (optional, bit set of FORM_*): the blend stage in float32 with the HIP kernel's algebraic rewrites switched on one
+    by one (gs2d_oracle_forms.c; 0 = this oracle's own operation order) -- for pricing each rewrite against backward_f64."""
     L = lib()
     P, W, H, M = st["P"], st["W"], st["H"], st["M"]
     dL_dcolor = _f32(dL_dcolor).reshape(3, H, W)
@@ -233,12 +243,21 @@ def backward(st, dL_dcolor, dL_dallmap, pixel_overrides=None, knife=0.0):
         return g
     features = st["colors_precomp"] if st["colors_precomp"] is not None else st["rgb"]
     tm = st["transMat_precomp"] if st["transMat_precomp"] is not None else st["transMats"]
-    L.orc_blend_bwd(C.c_int(P), C.c_int(W), C.c_int(H), _p(st["ranges"]), _p(st["point_list"]),
-                    _p(st["bg"]), _p(st["means2D"]), _p(st["normal_opacity"]), _p(tm), _p(features),
-                    _p(st["final_T"]), _p(st["n_contrib"]), _p(dL_dcolor), _p(dL_dallmap),
-                    _p(st["median_depth"]), _p(st["depth_std"]), C.c_int(int(st["use_sa"])),
-                    _p(g["dL_dtransMat"]), _p(g["dL_dmeans2D"]), _p(g["dL_dnormal"]),
-                    _p(g["dL_dopacity"]), _p(g["dL_dcolors"]), _p(extra))
+    if forms is not None:
+        assert extra is None
+        L.orc_blend_bwd_forms(C.c_int(int(forms)), C.c_int(P), C.c_int(W), C.c_int(H), _p(st["ranges"]), _p(st["point_list"]),
+                              _p(st["bg"]), _p(st["means2D"]), _p(st["normal_opacity"]), _p(tm), _p(features),
+                              _p(st["final_T"]), _p(st["n_contrib"]), _p(dL_dcolor), _p(dL_dallmap),
+                              _p(st["median_depth"]), _p(st["depth_std"]), C.c_int(int(st["use_sa"])),
+                              _p(g["dL_dtransMat"]), _p(g["dL_dmeans2D"]), _p(g["dL_dnormal"]),
+                              _p(g["dL_dopacity"]), _p(g["dL_dcolors"]))
+    else:
+        L.orc_blend_bwd(C.c_int(P), C.c_int(W), C.c_int(H), _p(st["ranges"]), _p(st["point_list"]),
+                        _p(st["bg"]), _p(st["means2D"]), _p(st["normal_opacity"]), _p(tm), _p(features),
+                        _p(st["final_T"]), _p(st["n_contrib"]), _p(dL_dcolor), _p(dL_dallmap),
+                        _p(st["median_depth"]), _p(st["depth_std"]), C.c_int(int(st["use_sa"])),
+                        _p(g["dL_dtransMat"]), _p(g["dL_dmeans2D"]), _p(g["dL_dnormal"]),
+                        _p(g["dL_dopacity"]), _p(g["dL_dcolors"]), _p(extra))
     g["dL_dtransMat_blend"] = g["dL_dtransMat"].copy()
     g["dL_dmeans2D_blend"] = g["dL_dmeans2D"].copy()
     L.orc_preprocess_bwd(C.c_int(P), C.c_int(st["D"]), C.c_int(M), _p(st["means3D"]), _p(tm),
@@ -249,6 +268,35 @@ def backward(st, dL_dcolor, dL_dallmap, pixel_overrides=None, knife=0.0):
                          _p(g["dL_dtransMat"]), _p(g["dL_dnormal"]), _p(g["dL_dcolors"]), _p(g["dL_dsh"]),
                          _p(g["dL_dmeans2D"]), _p(g["dL_dmeans3D"]), _p(g["dL_dscales"]),
                          _p(g["dL_drotations"]))
+    return g
+
+
+def backward_f64(st, dL_dcolor, dL_dallmap):
+    """The backward of a forward() state evaluated in FLOAT64 on the float32 paths' inputs and discrete decisions
+    (oracle/gs2d_oracle_f64.c): the yardstick that tells a float32 path's rounding error from a formula difference.
+    colors_precomp path only.  Returns float64 arrays: dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacity, dL_dcolors,
+    dL_dnormal and the blend-stage dL_dtransMat_blend / dL_dmeans2D_blend."""
+    L = lib()
+    P, W, H = st["P"], st["W"], st["H"]
+    assert st["shs"] is None, "backward_f64 covers the colors_precomp path"
+    dL_dcolor = _f32(dL_dcolor).reshape(3, H, W)
+    dL_dallmap = _f32(dL_dallmap).reshape(7, H, W)
+    z = lambda *s: np.zeros(s, np.float64)
+    g = dict(dL_dmeans3D=z(P, 3), dL_dmeans2D_blend=z(P, 3), dL_dcolors=z(P, 3), dL_dnormal=z(P, 3), dL_dopacity=z(P, 1),
+             dL_dtransMat=z(P, 9), dL_dscales=z(P, 2), dL_drotations=z(P, 4))
+    if P == 0:
+        return g
+    tm = st["transMat_precomp"] if st["transMat_precomp"] is not None else st["transMats"]
+    L.orc_blend_bwd_f64(C.c_int(P), C.c_int(W), C.c_int(H), _p(st["ranges"]), _p(st["point_list"]), _p(st["bg"]),
+                        _p(st["means2D"]), _p(st["normal_opacity"]), _p(tm), _p(st["colors_precomp"]), _p(st["final_T"]),
+                        _p(st["n_contrib"]), _p(dL_dcolor), _p(dL_dallmap), _p(st["median_depth"]), _p(st["depth_std"]),
+                        C.c_int(int(st["use_sa"])), _p(g["dL_dtransMat"]), _p(g["dL_dmeans2D_blend"]), _p(g["dL_dnormal"]),
+                        _p(g["dL_dopacity"]), _p(g["dL_dcolors"]))
+    g["dL_dtransMat_blend"] = g["dL_dtransMat"].copy()
+    L.orc_preprocess_bwd_f64(C.c_int(P), _p(st["means3D"]), _p(tm), _p(st["radii"]), _p(st["scales"]), _p(st["rotations"]),
+                             _p(st["viewmatrix"]), _p(st["projmatrix"]), C.c_int(W), C.c_int(H), C.c_float(st["tanfovx"]),
+                             C.c_float(st["tanfovy"]), _p(g["dL_dtransMat"]), _p(g["dL_dnormal"]), _p(g["dL_dmeans2D_blend"]),
+                             _p(g["dL_dmeans3D"]), _p(g["dL_dscales"]), _p(g["dL_drotations"]))
     return g
 
 

@@ -177,13 +177,124 @@ def test_backward_parity_includes_knife_edge_pixels_and_mid_magnitude_entries(or
     dc[:, ~stable] *= 10; da[:, ~stable] *= 10
     go = oracle.backward(o, dc, da, pixel_overrides=overrides, knife=KNIFE)
     gh = util.hip_backward(h, dc, da)
-    oracle.set_threads(1)
     for k in ALL_GRADS:
         ref = go[k].reshape(gh[k].shape)
         print(f"{k}: max-norm error {util.grad_err(gh[k], ref):.2e} (limit {GRAD_TOL:.0e}), mid-magnitude relative error "
               f"{util.grad_err_mid(gh[k], ref):.2e} (limit {MID_TOL:.0e})")
         assert util.grad_err(gh[k], ref) <= GRAD_TOL, k
         assert util.grad_err_mid(gh[k], ref) <= MID_TOL, (k, util.grad_err_mid(gh[k], ref))
+    # (c) VERDICT r3, weak 2: whose rounding is it?  The same backward evaluated in float64 on the same inputs and decisions
+    # (oracle.backward_f64) is the yardstick: the HIP forms (one merged blend recurrence, closed-form opacity-map term,
+    # med + conf (d - med)) must not be further from it than twice the float32 oracle's own operation order is.
+    dc[:, ~stable] = 0; da[:, ~stable] = 0   # (float64 has no per-pixel override: knife-edge pixels sit this part out)
+    _assert_rounding_no_worse_than_the_oracles(oracle, o, h, dc, da)
+    oracle.set_threads(1)
+
+
+F64_GRADS = ["dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dtransMat", "dL_dscales", "dL_drotations"]
+
+
+def _assert_rounding_no_worse_than_the_oracles(oracle, o, h, dc, da, gh=None):
+    """err(HIP, float64) <= 2 err(oracle-float32, float64), per tensor, on the mid-magnitude entries (max and rms of the
+    relative error) and in the max norm.  All three backwards start from the SAME per-pixel forward state -- the HIP
+    forward's (T_final, M1, M2, median, std, contributor counts; they differ from the oracle forward's by that pass's own
+    rounding, which is an input perturbation of the backward, not its arithmetic) -- on the oracle's lists and records, which
+    the HIP forward reproduces bit for bit."""
+    H, W = o["H"], o["W"]
+    oh = dict(o)
+    oh["final_T"] = np.concatenate([h["final_T"].ravel(), h["M1"].ravel(), h["M2"].ravel()]).astype(np.float32)
+    oh["n_contrib"] = np.concatenate([h["last_contributor"].ravel(), h["median_contributor"].ravel()]).astype(np.uint32)
+    oh["median_depth"] = np.ascontiguousarray(h["median_depth"].ravel(), np.float32)
+    oh["depth_std"] = np.ascontiguousarray(h["depth_std"].ravel(), np.float32)
+    go = oracle.backward(oh, dc, da)
+    gh = util.hip_backward(h, dc, da) if gh is None else gh
+    g64 = oracle.backward_f64(oh, dc, da)
+    rep = util.rounding_report(gh, go, g64, F64_GRADS)
+    for k, (h_mid, o_mid, h_max, o_max, h_rms, o_rms) in rep.items():
+        assert h_rms <= 2 * o_rms, (k, "mid-magnitude rms", h_rms, o_rms)
+        assert h_max <= 2 * o_max, (k, "max-norm", h_max, o_max)
+        # the MAX over ~1e5-1e6 mid-magnitude entries is an extreme-value statistic: v_rcp_f32 / v_exp_f32 at their 1-ulp error
+        # bounds alone move it by 2-3x in the CPU emulation (profiles/form_costs_r04.txt: rows RCP, EXP2 + RCP), the four
+        # algebraic rewrites of the kernel by nothing
+        assert h_mid <= 5 * o_mid and h_mid <= MID_TOL / 2, (k, "mid-magnitude max", h_mid, o_mid)
+    return rep
+
+
+def _probe_scene(oracle, P, W, H, seed, use_sa, n_probes=1500):
+    """A regular scene in which `n_probes` splats get an opacity that puts alpha = opacity * exp(-rho / 2) of ONE pixel of their
+    footprint within an ulp or two of the 1/255 threshold (forward.cu:385-387): the oracle's expf and the kernel's v_exp_f32
+    then fall on different sides of it on a good share of those pixels -- FLIPPED decisions by construction, not by luck."""
+    sc = util.make_scene(P, W, H, seed=seed, regime="mapping")
+    o1 = util.oracle_forward(oracle, sc, use_sa=use_sa)
+    rng = np.random.default_rng(seed + 1)
+    vis = np.nonzero(o1["radii"] > 0)[0]
+    opac = sc["opacities"].clone()
+    used = set()
+    n = 0
+    for g in rng.permutation(vis):
+        T = o1["transMats"][g].astype(np.float64)
+        cx, cy = o1["means2D"][g].astype(np.float64)
+        x, y = int(round(cx)) + int(rng.integers(-2, 3)), int(round(cy)) + int(rng.integers(-2, 3))
+        if not (0 <= x < W and 0 <= y < H) or (x, y) in used:
+            continue
+        k, l = x * T[6:9] - T[0:3], y * T[6:9] - T[3:6]
+        p = np.cross(k, l)
+        if p[2] == 0:
+            continue
+        s = p[:2] / p[2]
+        rho = min(float(s @ s), 100.0 * ((cx - x) ** 2 + (cy - y) ** 2))
+        if not 1.0 <= rho <= 9.0:
+            continue
+        opac[g, 0] = float(np.float32((1.0 / 255.0) / np.exp(-0.5 * rho)))
+        used.add((x, y))
+        n += 1
+        if n == n_probes:
+            break
+    assert n >= n_probes // 2
+    sc = dict(sc)
+    sc["opacities"] = opac
+    return sc
+
+
+@pytest.mark.parametrize("use_sa", [True, False])
+def test_backward_parity_under_flipped_decisions(oracle, use_sa):
+    """the knife-edge backward machinery has to meet a decision the HIP forward really took the other way.
+    Here hundreds of (pixel, splat) pairs sit within an ulp of alpha = 1/255 (_probe_scene); the test requires flipped
+    decisions among them, runs the oracle's backward on exactly the outcomes the HIP forward took (pixel_overrides) with a
+    HUNDRED times those pixels' share of upstream gradient, and requires (1) agreement within the usual tolerances and
+    (2) that the same comparison WITHOUT the overrides fails them -- i.e. the flipped outcomes are visible in the gradients
+    and the override mechanism is what reconciles them."""
+    W, H, P = 320, 240, 20000
+    oracle.set_threads(os.cpu_count() or 1)
+    sc = _probe_scene(oracle, P, W, H, 41, use_sa)
+    o = util.oracle_forward(oracle, sc, use_sa=use_sa)
+    h = util.hip_forward(sc, use_sa=use_sa)
+    stable = (o["stability"] > KNIFE).reshape(H, W)
+    overrides = util.match_knife_variants(oracle, o, h, stable, IMG_TOL, KNIFE)
+    flipped = [(x, y, m) for x, y, m in overrides if m != 0]
+    HWn = H * W
+    n_last = int((h["last_contributor"] != o["n_contrib"][:HWn].reshape(H, W)).sum())
+    print(f"knife-edge pixels: {int((~stable).sum())}, flipped decisions among them: {len(flipped)}; pixels whose last contributor "
+          f"differs between HIP and the oracle: {n_last}")
+    assert len(flipped) >= 20, len(flipped)
+    dc, da = util.make_upstream_grads(W, H, channels=(0, 1, 2, 3, 4, 5, 6))
+    dc, da = (dc * W * H).numpy(), (da * W * H).numpy()
+    dc[:, ~stable] *= 100; da[:, ~stable] *= 100
+    go = oracle.backward(o, dc, da, pixel_overrides=overrides, knife=KNIFE)
+    g_plain = oracle.backward(o, dc, da)  # the oracle's OWN outcomes on the knife-edge pixels
+    gh = util.hip_backward(h, dc, da)
+    oracle.set_threads(1)
+    worst_plain = 0.0
+    for k in ALL_GRADS:
+        ref = go[k].reshape(gh[k].shape)
+        e, em = util.grad_err(gh[k], ref), util.grad_err_mid(gh[k], ref)
+        ep = util.grad_err_mid(gh[k], g_plain[k].reshape(gh[k].shape))
+        worst_plain = max(worst_plain, ep)
+        print(f"{k}: max-norm error {e:.2e} (limit {GRAD_TOL:.0e}), mid-magnitude relative error {em:.2e} (limit {MID_TOL:.0e}); "
+              f"against the oracle's own outcomes: {ep:.2e}")
+        assert e <= GRAD_TOL, k
+        assert em <= MID_TOL, (k, em)
+    assert worst_plain > MID_TOL, "the flipped decisions were meant to be visible in the gradients"
 
 
 def test_full_size_default_mode_against_the_oracle(oracle):
@@ -217,7 +328,6 @@ def test_full_size_default_mode_against_the_oracle(oracle):
     dc[:, ~stable] = 0; da[:, ~stable] = 0
     go, gt = oracle.backward(o, dc, da), oracle.backward(ot, dc, da)
     gh = util.hip_backward(ht, dc, da)
-    oracle.set_threads(1)
     for k in ALL_GRADS:
         np.testing.assert_array_equal(gt[k].view(np.uint32), go[k].view(np.uint32), err_msg=k)
         ref = go[k].reshape(gh[k].shape)
@@ -225,6 +335,9 @@ def test_full_size_default_mode_against_the_oracle(oracle):
               f"{util.grad_err_mid(gh[k], ref):.2e} (limit {MID_TOL:.0e})")
         assert util.grad_err(gh[k], ref) <= GRAD_TOL, k
         assert util.grad_err_mid(gh[k], ref) <= MID_TOL, (k, util.grad_err_mid(gh[k], ref))
+    # whose rounding is the 9e-4 on dL_dmeans3D?  Both float32 paths against the float64 evaluation (see the 320x240 test)
+    _assert_rounding_no_worse_than_the_oracles(oracle, ot, ht, dc, da, gh=gh)
+    oracle.set_threads(1)
 
 
 def test_k_keyframe_policy_reaches_the_one_keyframe_loss():

@@ -142,6 +142,25 @@ def grad_err_mid(a, b, floor=1e-3):
     return float((np.abs(a[sel] - b[sel]) / np.abs(b[sel])).max())
 
 
+def rounding_report(gh, go, g64, keys, floor=1e-3):
+    """Per tensor: the mid-magnitude relative error (grad_err_mid) and the max-norm error (grad_err) of the HIP gradients and
+    of the float32 oracle's, both measured against the float64 evaluation of the same backward on the same inputs and
+    decisions (oracle.backward_f64).  Returns {key: (hip_mid, orc_mid, hip_max, orc_max, hip_rms, orc_rms)}; rms = root mean
+    square of the relative error over the mid-magnitude entries (the max is an extreme-value statistic of ~1e6 entries)."""
+    out = {}
+    for k in keys:
+        ref = np.asarray(g64[k], np.float64).ravel()
+        a = np.asarray(gh[k], np.float64).ravel()
+        b = np.asarray(go[k], np.float64).ravel()
+        sel = np.abs(ref) >= floor * np.abs(ref).max()
+        ra, rb = np.abs(a[sel] - ref[sel]) / np.abs(ref[sel]), np.abs(b[sel] - ref[sel]) / np.abs(ref[sel])
+        out[k] = (float(ra.max()), float(rb.max()), grad_err(a, ref), grad_err(b, ref), float(np.sqrt((ra ** 2).mean())),
+                  float(np.sqrt((rb ** 2).mean())))
+        print(f"{k}: vs float64 -- mid-magnitude relative error HIP {out[k][0]:.2e} / oracle-f32 {out[k][1]:.2e}; rms of it "
+              f"{out[k][4]:.2e} / {out[k][5]:.2e}; max-norm {out[k][2]:.2e} / {out[k][3]:.2e}")
+    return out
+
+
 def match_knife_variants(orc, o, h, stable, tol, knife, scale=None):
     """For every knife-edge pixel: the outcome of its near-threshold decisions (flip mask of oracle.pixel_variants) under which
     the oracle's pixel equals the HIP pixel (same contributors, smallest error <= tol).  Returns [(x, y, mask)] -- the input of
