@@ -183,6 +183,9 @@ PREWARM_SECONDS = 1.6   # target duration
 PREWARM_DONE = 0        # steps actually run (reported as config.prewarm_steps)
 
 
+HOST_CPU_FRACTION = None
+
+
 def timed(one_step, steps, warmup, world, dev, prewarm=True):
     def sync():
         if _dist_on(world):
@@ -220,11 +223,18 @@ def timed(one_step, steps, warmup, world, dev, prewarm=True):
     for _ in range(warmup):
         one_step()
     sync()
+    global HOST_CPU_FRACTION
+    c0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(steps):
         one_step()
+    c1 = time.process_time()  # (before the final synchronize, which spins in the HIP runtime)
+    t1 = time.perf_counter()
     sync()
     elapsed = time.perf_counter() - t0
+    # CPU time of this process (all its threads) per wall second while it issued the timed steps: ~1.0 = a core busy
+    # throughout (a spinning wait), less = the host slept through part of every step (gs2d_api.hip, wait_total)
+    HOST_CPU_FRACTION = round((c1 - c0) / max(t1 - t0, 1e-9), 3)
     if _dist_on(world):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -328,6 +338,7 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
     if PREWARM_STEPS > 0 and not args.no_extra_legs:
         cold_elapsed = timed(one_step, args.steps, args.warmup, world, dev, prewarm=False)
     elapsed = timed(one_step, args.steps, args.warmup, world, dev)
+    host_cpu = HOST_CPU_FRACTION
     # The same steps in the contract's binning mode (gs2d_set_reference_binning(1): the reference's 3-sigma tile
     # rectangles, num_rendered and the sorted lists bit-identical to the reference's), on the now warm card.
     ref_elapsed = None
@@ -460,7 +471,9 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
                                    "instances, lists bit-identical to the reference's)", "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
                    "allreduce_chunks": ba.overlap_chunks if _dist_on(world) else None,
                    "allreduce_chunks_tuning_ms": {str(k): round(v, 4) for k, v in tuned.items()} or None,
-                   "allreduce_tuning_error": tune_error},
+                   "allreduce_tuning_error": tune_error,
+                   "host_cpu_fraction": host_cpu,
+                   "launch_ahead": bool(_lib.lib().gs2d_get_launch_ahead())},
         "roofline": roofline, "cpu_baseline": cpu_baseline,
     }
 
@@ -527,6 +540,7 @@ def slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world):
         step_desc = "render + fused mapping loss (value + gradients in one call) + backward (gradients written into the bucket) + fused Adam over the SoA"
         metric = f"mapping iterations/sec @ {W}x{H}, {P // 1000}k Gaussians"
     elapsed = timed(one_step, args.steps, args.warmup, world, dev)
+    host_cpu = HOST_CPU_FRACTION
     # per-stage device time of the operator's kernels inside the iteration (hipEvents on the launch stream; separate, untimed leg)
     L = _lib.lib()
     L.gs2d_stage_timing_enable(1)
@@ -544,7 +558,7 @@ def slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {W}x{H} / {P} Gaussians, {args.workload} iteration (BASELINE.json configs[2] loop shape), "
                                    f"use_sa={use_sa}", "step": step_desc, "parallelism": "single GPU", "prewarm_steps": PREWARM_DONE,
-                       "stage_ms": stage_ms},
+                       "stage_ms": stage_ms, "host_cpu_fraction": host_cpu},
             "roofline": None, "cpu_baseline": None}
 
 

@@ -11,7 +11,7 @@ EXPORTS = ["gs2d_forward", "gs2d_backward", "gs2d_forward_posed", "gs2d_backward
            "gs2d_image_bytes", "gs2d_binning_bytes", "gs2d_geometry_layout", "gs2d_binning_layout",
            "gs2d_image_layout", "gs2d_last_error", "gs2d_build_info", "gs2d_stage_timing_enable",
            "gs2d_stage_timing_read", "gs2d_slam_loss", "gs2d_adam_step", "gs2d_pose_quat", "gs2d_backward_staged", "gs2d_set_deterministic",
-           "gs2d_get_deterministic", "gs2d_set_reference_binning", "gs2d_get_reference_binning", "gs2d_forward_batch",
+           "gs2d_get_deterministic", "gs2d_set_reference_binning", "gs2d_get_reference_binning", "gs2d_set_launch_ahead", "gs2d_get_launch_ahead", "gs2d_forward_batch",
            "gs2d_backward_batch", "gs2d_stage_timing_read_abs"]
 MAX_FRAMES = 8  # GS2D_MAX_FRAMES
 
@@ -89,6 +89,8 @@ def lib():
     L.gs2d_set_deterministic.argtypes = [i]
     L.gs2d_get_deterministic.restype = i
     L.gs2d_set_reference_binning.argtypes = [i]
+    L.gs2d_set_launch_ahead.argtypes = [i]
+    L.gs2d_get_launch_ahead.restype = i
     L.gs2d_get_reference_binning.restype = i
     L.gs2d_stage_timing_enable.argtypes = [i]
     L.gs2d_stage_timing_read.restype = i

@@ -5,6 +5,7 @@
 #include "../../include/gs2d_rasterizer.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <chrono>
 #include <string>
@@ -87,6 +88,12 @@ StageTimer g_timer;
 // deterministic backward (opt-in, process-wide): must not change between a forward and its backward
 std::atomic<int> g_deterministic{0};
 std::atomic<int> g_reference_binning{0};
+// 1 (default): a single-frame forward enqueues ALL its kernels before the host looks at num_rendered (the kernels behind
+// duplicate read the count on the device, DevBin); 0: the round-3 order (duplicate, host wait, the rest) -- kept for A/B
+// measurements and as the path debug mode, the deterministic mode and images of more than 4096 tiles take anyway.
+// (GS2D_LAUNCH_AHEAD=0 in the environment: initial value 0 -- for A/B runs of one build)
+static int launch_ahead_default() { const char* e = getenv("GS2D_LAUNCH_AHEAD"); return (e && e[0] == '0') ? 0 : 1; }
+std::atomic<int> g_launch_ahead{launch_ahead_default()};
 
 // pinned host word for the num_rendered read-back (one per host thread)
 struct PinnedWord {
@@ -207,6 +214,8 @@ int gs2d_stage_timing_read_abs(float ms[18])
 void gs2d_set_deterministic(int on) { g_deterministic.store(on != 0); }
 int gs2d_get_deterministic(void) { return g_deterministic.load(); }
 void gs2d_set_reference_binning(int on) { g_reference_binning.store(on != 0); }
+void gs2d_set_launch_ahead(int on) { g_launch_ahead.store(on != 0); }
+int gs2d_get_launch_ahead(void) { return g_launch_ahead.load(); }
 int gs2d_get_reference_binning(void) { return g_reference_binning.load(); }
 
 const char* gs2d_build_info(void) { return "gs2d-hip gfx950 strict-fp (fp-contract=off) " __DATE__; }
@@ -261,6 +270,10 @@ struct FwdFrame {    // one frame: inputs, then the state the phases hand on
     bool fused_sort = false;     // the blend kernel sorts this frame's tile lists itself (phase -1)
     bool spec = false;           // duplicate runs before the host knows num_rendered (single-pass binning: tiles <= GS2D_BIN_MAX_TILES)
     bool store_pending = false;  // a kernel WILL store into `pinned`: every return path first waits for that store
+    bool ahead = false;          // the stages behind duplicate were launched with the count on the device (fwd_phase_b), the host
+                                 // has not looked at num_rendered yet: fwd_phase_d does, after the blend kernel is enqueued
+    int cap = 0;                 // ahead: the capacity the binning chunk `bin` was sized for
+    bool det = false;
     int R = 0;
     gs2d::BlendFwdFrame bf;
 };
@@ -287,13 +300,40 @@ int fwd_validate(const FwdShared& c)
 #ifndef GS2D_SPIN_BEFORE_YIELD_US
 #define GS2D_SPIN_BEFORE_YIELD_US 1000
 #endif
-bool wait_total(FwdFrame& f, hipStream_t s)
+// 1 (default): the launch-ahead forward's one wait (fwd_phase_d) SLEEPS through most of itself instead of spinning.  In steady
+// state the host runs a step ahead and the wait is as long as what is left of the previous step's backward (~0.2 ms per step at
+// the bench size); the thread keeps a running mean of its recent waits, sleeps once for that mean minus GS2D_NAP_MARGIN_US (a
+// timer's slack plus a wake-up: a sleep that overshoots the count's arrival delays the host's next launches, measured -2 % at
+// 640x480 / 200k with plain 20-us naps) and polls the rest.  Short waits (idle GPU, small scenes) never sleep.
+// GS2D_NAP_WAIT=0 in the environment: spin only, as the round-3 order does.
+static int nap_wait_default() { const char* e = getenv("GS2D_NAP_WAIT"); return (e && e[0] == '0') ? 0 : 1; }
+std::atomic<int> g_nap_wait{nap_wait_default()};
+#ifndef GS2D_NAP_MARGIN_US
+#define GS2D_NAP_MARGIN_US 110.0
+#endif
+thread_local double g_wait_mean_us = 0.0;
+
+bool wait_total(FwdFrame& f, hipStream_t s, bool may_nap = false)
 {
     if (!f.store_pending) return true;
     f.store_pending = false;
     const auto t0 = std::chrono::steady_clock::now();
     uint64_t spins = 0;
     bool yielding = false;
+    if (may_nap && g_nap_wait.load() != 0) {
+        const double nap_us = g_wait_mean_us - GS2D_NAP_MARGIN_US;
+        if (nap_us > 20.0 && *f.pinned == 0xFFFFFFFFu)
+            std::this_thread::sleep_for(std::chrono::nanoseconds((long long)(nap_us * 1e3)));
+        while (*f.pinned == 0xFFFFFFFFu) {
+            cpu_relax();
+            if ((++spins & 0x3FFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2))
+                return hipStreamSynchronize(s) == hipSuccess && *f.pinned != 0xFFFFFFFFu;
+        }
+        const double w = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        // running mean of the waits that did NOT oversleep much; an overslept one (w far above the mean) pulls it up slowly only
+        g_wait_mean_us = g_wait_mean_us == 0.0 ? w : 0.9 * g_wait_mean_us + 0.1 * (w < 2.0 * g_wait_mean_us + 50.0 ? w : g_wait_mean_us);
+        return true;
+    }
     while (*f.pinned == 0xFFFFFFFFu) {
         if (yielding) std::this_thread::yield(); else cpu_relax();
         if ((++spins & (yielding ? 0x3Fu : 0x3FFu)) == 0) {
@@ -370,7 +410,7 @@ int fwd_phase_a(const FwdShared& c, FwdFrame& f, int slot)
     return 0;
 }
 
-int fwd_phase_b(const FwdShared& c, FwdFrame& f, int slot)
+int fwd_phase_b(const FwdShared& c, FwdFrame& f, int slot, bool allow_ahead = true)
 {
     const int debug = c.debug;
     hipStream_t s = c.s;
@@ -407,15 +447,43 @@ int fwd_phase_b(const FwdShared& c, FwdFrame& f, int slot)
         if (!bin_pre) return fail_msg("binning allocation failed");
         const BinLayout B0 = bin_layout(C0, det, C0);
         *f.pinned = 0xFFFFFFFFu;
+        // launch-ahead: the kernels behind duplicate take the count from `total_dev` (device word in the geometry chunk's scan
+        // scratch, written by duplicate's last workgroup next to the pinned host word) and are enqueued right here -- the
+        // GPU never waits for the host between duplicate and the blend; the host looks at the count in fwd_phase_d
+        const bool ahead = allow_ahead && g_launch_ahead.load() != 0 && !debug && !det;
+        uint32_t* total_dev = scan_tmp + (P + 255) / 256 + 8;
         g_timer.begin(ST_DUPLICATE, s);
         gs2d::launch_duplicate(P, rect, depths, tiles_touched, scan_tmp, 0, point_offsets, cam.gx, (uint64_t*)(bin_pre + B0.keys_alt),
-                               (uint32_t*)(bin_pre + B0.vals_alt), (uint32_t)C0, (uint32_t*)f.pinned, s);
+                               (uint32_t*)(bin_pre + B0.vals_alt), (uint32_t)C0, (uint32_t*)f.pinned, s, ahead ? total_dev : nullptr);
         g_timer.end(ST_DUPLICATE, s);
         {
             const hipError_t le = hipGetLastError();
             if (le != hipSuccess) return fail("duplicate", le);  // nothing was enqueued: nothing will store into the word
         }
         f.store_pending = true;
+        if (ahead) {
+            const gs2d::DevBin db = {bin_pre, total_dev, (uint32_t)C0, 0};
+            uint2* ranges = (uint2*)(img + IL.ranges);
+            const int tile_bits = (int)higher_msb((uint32_t)(cam.gx * cam.gy));
+            g_timer.begin(ST_SORT, s);
+            gs2d::launch_bin_by_tile_dev(db, IL.tiles, tile_bits, ranges, s);
+            // depth-sort capacity class from the count this shape had last time (any class is correct: longer lists take the
+            // global-memory variant); the sort is fused into the blend kernel at the class its LDS holds anyway
+            const long long Rg = same_shape ? (long long)last.R : (long long)C0;
+            const int cap_class = gs2d::tile_sort_capacity(Rg, IL.tiles);
+            f.fused_sort = cap_class == GS2D_FUSED_SORT_CAP;
+            if (!f.fused_sort) gs2d::launch_tile_depth_sort_dev(db, IL.tiles, ranges, cap_class, 0, s);
+            g_timer.end(ST_SORT, s);
+            GS2D_STAGE("bin by tile (count on the device)");
+            f.ahead = true; f.cap = C0; f.det = false;
+            f.bin = bin_pre;
+            f.bf.ranges = ranges; f.bf.point_list = nullptr; f.bf.rec = (const float4*)(geom + GL.rec);
+            f.bf.out_color = f.out_color; f.bf.out_others = f.out_others; f.bf.pix_state = (float*)(img + IL.pix);
+            f.bf.hits = nullptr; f.bf.hits4 = nullptr; f.bf.zero = (float4*)(geom + GL.grad_rec);
+            f.bf.keys = nullptr; f.bf.keys_alt = nullptr; f.bf.vals_alt = nullptr;
+            f.bf.dev = db;
+            return 0;
+        }
     }
     if (!wait_total(f, s)) return fail_msg("num_rendered read-back failed");
     if (debug) GS2D_CHECK(hipStreamSynchronize(s), f.spec ? "duplicate" : "scan");
@@ -493,6 +561,7 @@ int fwd_phase_b(const FwdShared& c, FwdFrame& f, int slot)
     f.bf.hits = (uint8_t*)(bin + BL.hits); f.bf.hits4 = (uint8_t*)(bin + BL.hits4);
     f.bf.zero = (float4*)(geom + GL.grad_rec);
     f.bf.keys = keys; f.bf.keys_alt = keys_alt; f.bf.vals_alt = vals_alt;
+    f.bf.dev = gs2d::DevBin{nullptr, nullptr, 0u, 0};
     return 0;
 }
 
@@ -612,6 +681,7 @@ int fwd_batch_fused(const FwdShared& c, FwdFrame* f, int K)
         o.hits = (uint8_t*)(bn + BL.hits); o.hits4 = (uint8_t*)(bn + BL.hits4);
         o.zero = (float4*)(f[k].geom + GL.grad_rec);
         o.keys = b.keys; o.keys_alt = b.keys_alt; o.vals_alt = b.vals_alt;
+        o.dev = gs2d::DevBin{nullptr, nullptr, 0u, 0};
     }
     if (debug) GS2D_CHECK(hipStreamSynchronize(s), "duplicate (batch)");
     for (int k = K; k < GS2D_MAX_BATCH; k++) bin.f[k] = bin.f[0];
@@ -645,6 +715,7 @@ int fwd_phase_c(const FwdShared& c, FwdFrame* frames, int K)
                            fused ? GS2D_FUSED_SORT_CAP : 0, debug ? 1 : 0, s);
     const bool det = g_deterministic.load() != 0;
     for (int k = 0; k < K; k++) {
+        if (frames[k].ahead) continue;  // num_rendered not known yet: fwd_phase_d writes the record
         FwdRecord fr;
         fr.geom = frames[k].geom; fr.bin = frames[k].bin; fr.bin_bytes = frames[k].bin_bytes; fr.det = det ? 1 : 0;
         fr.R = frames[k].R; fr.P = c.P; fr.clean = true;
@@ -652,6 +723,39 @@ int fwd_phase_c(const FwdShared& c, FwdFrame* frames, int K)
     }
     g_timer.end(ST_BLEND_FWD, s);
     GS2D_STAGE("blend_fwd");
+    return 0;
+}
+
+// Launch-ahead forward, last step: every kernel of the forward is enqueued; NOW the host looks at num_rendered (the word
+// duplicate_kernel's last workgroup stored -- long there unless the GPU is backed up behind earlier work, in which case the
+// wait costs the GPU nothing: its queue is full).  A count within the chunk's capacity: done, the record is written.  A count
+// beyond it (first call of a shape, a scene that grew by more than 12.5 % between calls): the kernels behind duplicate saw the
+// same number and touched nothing; duplicate, binning and blend run once more in a chunk of the exact size, in stream order.
+int fwd_phase_d(const FwdShared& c, FwdFrame& f, int slot)
+{
+    hipStream_t s = c.s;
+    if (!wait_total(f, s, /*may_nap=*/true)) return fail_msg("num_rendered read-back failed");
+    const uint32_t num_rendered_u = *f.pinned;
+    if (num_rendered_u == 0xFFFFFFFFu) return fail_msg("num_rendered read-back failed");
+    if (num_rendered_u > 0x7fffffffu) return fail_msg("num_rendered overflows int32");
+    const int R = (int)num_rendered_u;
+    LastCount& last = g_last[slot];
+    last.P = c.P; last.W = c.width; last.H = c.height; last.R = num_rendered_u;
+    f.ahead = false;
+    if (R <= f.cap) {
+        f.R = R;
+        f.bin_bytes = bin_layout(R, false, f.cap).total;
+    } else {
+        // once more with the count known: the round-3 order from duplicate on (fwd_phase_b does exactly that when the
+        // launch-ahead switch is off; the pinned word is re-armed by it and written again by the new duplicate launch)
+        // (last.R is the exact count now, so the second pass's chunk is large enough)
+        if (fwd_phase_b(c, f, slot, /*allow_ahead=*/false) < 0) return -1;
+        if (fwd_phase_c(c, &f, 1) < 0) return -1;
+        return 0;  // (fwd_phase_c wrote the record)
+    }
+    FwdRecord fr;
+    fr.geom = f.geom; fr.bin = f.bin; fr.bin_bytes = f.bin_bytes; fr.det = 0; fr.R = f.R; fr.P = c.P; fr.clean = true;
+    g_fwd.add(fr);
     return 0;
 }
 
@@ -689,7 +793,8 @@ int gs2d_forward_posed(gs2d_alloc_fn geometry_alloc, void* geometry_user, gs2d_a
     f.out_color = out_color; f.out_others = out_others; f.radii = radii;
     if (fwd_phase_a(c, f, 0) < 0) { (void)wait_total(f, c.s); return -1; }
     if (fwd_phase_b(c, f, 0) < 0) { (void)wait_total(f, c.s); return -1; }
-    if (fwd_phase_c(c, &f, 1) < 0) return -1;
+    if (fwd_phase_c(c, &f, 1) < 0) { (void)wait_total(f, c.s); return -1; }
+    if (f.ahead && fwd_phase_d(c, f, 0) < 0) { (void)wait_total(f, c.s); return -1; }
     return f.R;
 }
 

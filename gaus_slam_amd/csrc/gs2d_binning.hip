@@ -68,7 +68,7 @@ __device__ __forceinline__ void
 duplicate_body(int P, const ushort4* __restrict__ rect, const float* __restrict__ depths,
                const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_sums, int scanned,
                uint32_t* __restrict__ point_offsets, int gx, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-               uint32_t capacity, uint32_t* __restrict__ total_host)
+               uint32_t capacity, uint32_t* __restrict__ total_host, uint32_t* __restrict__ total_dev = nullptr)
 {
     // The prefix sum of tiles_touched (rasterizer_impl.cu:283) is finished here: the preprocess kernel left one sum per
     // 256 Gaussians; this workgroup (the same 256 Gaussians) adds up the sums of the blocks before it -- at most a few
@@ -92,6 +92,7 @@ duplicate_body(int P, const ushort4* __restrict__ rect, const float* __restrict_
     if (!scanned && total_host != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         // a relaxed system-scope store into coherent pinned memory: the host polls the word (0xFFFFFFFF = not yet)
         const uint32_t total = block_offset + own_total;
+        if (total_dev != nullptr) *total_dev = total;  // for the kernels behind this one (DevBin): visible at the kernel boundary
         __hip_atomic_store(total_host, total == 0xFFFFFFFFu ? 0xFFFFFFFEu : total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (idx >= P) return;
@@ -118,9 +119,9 @@ __global__ void __launch_bounds__(256)
 duplicate_kernel(int P, const ushort4* __restrict__ rect, const float* __restrict__ depths,
                  const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_sums, int scanned,
                  uint32_t* __restrict__ point_offsets, int gx, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                 uint32_t capacity, uint32_t* __restrict__ total_host)
+                 uint32_t capacity, uint32_t* __restrict__ total_host, uint32_t* __restrict__ total_dev)
 {
-    duplicate_body(P, rect, depths, tiles_touched, block_sums, scanned, point_offsets, gx, keys, vals, capacity, total_host);
+    duplicate_body(P, rect, depths, tiles_touched, block_sums, scanned, point_offsets, gx, keys, vals, capacity, total_host, total_dev);
 }
 __global__ void __launch_bounds__(256) duplicate_batch_kernel(int P, int gx, const gs2d::BinFrames tab)
 {
@@ -329,7 +330,7 @@ bin_scatter_body(const uint64_t* __restrict__ keys_in, const uint32_t* __restric
         for (int t = t0; t < t1; t++) {
             const uint32_t tot = tile_total[t];
             const uint32_t c0 = lds[t], c1 = lds[ntiles + t], c2 = lds[2 * ntiles + t];
-            const uint32_t start = running + offs_excl[(size_t)t * nblocks + blockIdx.x];
+            const uint32_t start = running + (nblocks > 0 ? offs_excl[(size_t)t * nblocks + blockIdx.x] : 0u);
             lds[t] = start; lds[ntiles + t] = start + c0; lds[2 * ntiles + t] = start + c0 + c1; lds[3 * ntiles + t] = start + c0 + c1 + c2;
             // tile ranges = boundaries of the scanned histogram (rasterizer_impl.cu:116-138 semantics)
             if (blockIdx.x == 0) ranges[t] = tot ? make_uint2(running, running + tot) : make_uint2(0u, 0u);
@@ -372,6 +373,57 @@ __global__ void __launch_bounds__(BIN_T) bin_scatter_batch_kernel(int ntiles, in
     if ((int)blockIdx.x >= f.nblocks) return;
     bin_scatter_body(f.keys_unsorted, f.vals_unsorted, f.keys, f.point_list, f.R, ntiles, nbits, f.hist,
                      f.hist + (size_t)ntiles * f.nblocks, f.nblocks, f.ranges);
+}
+
+// The single-frame kernels with the count read on the device (DevBin, gs2d_common.h): same bodies, pointers from the layout of
+// the count duplicate_kernel stored; a count beyond the chunk's capacity means "do nothing" (the host will come back).
+struct DevBinPtrs {
+    int R, nblocks;
+    const uint64_t* keys_unsorted; const uint32_t* vals_unsorted;
+    uint64_t* keys; uint32_t* point_list; uint64_t* keys_alt; uint32_t* vals_alt; uint32_t* hist;
+};
+__device__ __forceinline__ bool dev_bin_ptrs(const gs2d::DevBin& db, DevBinPtrs* o)
+{
+    const uint32_t R = *db.R_dev;
+    if (R > db.cap) return false;
+    const BinLayout L = bin_layout((int)R, db.det != 0, (int)db.cap);
+    o->R = (int)R;
+    o->nblocks = ((int)R + BIN_ITEMS - 1) / BIN_ITEMS;
+    o->keys = (uint64_t*)(db.base + L.keys); o->point_list = (uint32_t*)(db.base + L.point_list);
+    o->keys_alt = (uint64_t*)(db.base + L.keys_alt); o->vals_alt = (uint32_t*)(db.base + L.vals_alt);
+    o->keys_unsorted = o->keys_alt; o->vals_unsorted = o->vals_alt;  // one pass: the unsorted pairs sit in the "alt" buffers
+    o->hist = (uint32_t*)(db.base + L.hist);
+    return true;
+}
+__global__ void __launch_bounds__(BIN_T) bin_hist_dev_kernel(const gs2d::DevBin db, int ntiles)
+{
+    DevBinPtrs p;
+    if (!dev_bin_ptrs(db, &p) || (int)blockIdx.x >= p.nblocks) return;
+    bin_hist_body(p.keys_unsorted, p.R, ntiles, p.hist, p.nblocks);
+}
+__global__ void __launch_bounds__(256) bin_row_scan_dev_kernel(const gs2d::DevBin db, int ntiles)
+{
+    DevBinPtrs p;
+    if (!dev_bin_ptrs(db, &p)) return;
+    bin_row_scan_body(p.hist, ntiles, p.nblocks, p.hist + (size_t)ntiles * p.nblocks);  // (no instances: every row total is 0)
+}
+__global__ void __launch_bounds__(BIN_T) bin_scatter_dev_kernel(const gs2d::DevBin db, int ntiles, int nbits, uint2* __restrict__ ranges)
+{
+    DevBinPtrs p;
+    if (!dev_bin_ptrs(db, &p)) return;
+    // workgroup 0 always runs: it writes the tile ranges (all empty when there are no instances)
+    if ((int)blockIdx.x >= p.nblocks && blockIdx.x != 0) return;
+    bin_scatter_body(p.keys_unsorted, p.vals_unsorted, p.keys, p.point_list, p.R, ntiles, nbits, p.hist,
+                     p.hist + (size_t)ntiles * p.nblocks, p.nblocks, ranges);
+}
+__global__ void __launch_bounds__(256)
+tile_depth_sort_dev_kernel(const gs2d::DevBin db, const uint2* __restrict__ ranges, int cap, int write_keys)
+{
+    extern __shared__ uint32_t dyn[];
+    __shared__ uint32_t wcnt[4][256];
+    DevBinPtrs p;
+    if (!dev_bin_ptrs(db, &p) || p.R == 0) return;
+    tile_depth_sort_body(blockIdx.x, dyn, wcnt, ranges, p.keys, p.point_list, p.keys_alt, p.vals_alt, cap, 1, write_keys);
 }
 
 __global__ void __launch_bounds__(256)
@@ -425,10 +477,10 @@ void launch_offsets_blocksums(int P, uint32_t* block_sums, uint32_t* total_dev, 
 
 void launch_duplicate(int P, const ushort4* rect, const float* depths, const uint32_t* tiles_touched,
                       const uint32_t* block_sums, int scanned, uint32_t* point_offsets, int gx, uint64_t* keys, uint32_t* vals,
-                      uint32_t capacity, uint32_t* total_host, hipStream_t s)
+                      uint32_t capacity, uint32_t* total_host, hipStream_t s, uint32_t* total_dev)
 {
     hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, rect, depths, tiles_touched, block_sums, scanned,
-                       point_offsets, gx, keys, vals, capacity, total_host);
+                       point_offsets, gx, keys, vals, capacity, total_host, total_dev);
 }
 
 void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int begin_bit,
@@ -466,6 +518,21 @@ bool launch_bin_by_tile(int R, int tiles, int nbits, const uint64_t* keys_in, co
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblocks), dim3(BIN_T), (size_t)tiles * 16, s, keys_in, vals_in, keys_out, vals_out,
                        R, tiles, nbits, hist, tile_total, nblocks, ranges);
     return true;
+}
+
+void launch_bin_by_tile_dev(const DevBin& db, int tiles, int nbits, uint2* ranges, hipStream_t s)
+{
+    int grid = ((int)db.cap + BIN_ITEMS - 1) / BIN_ITEMS;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(bin_hist_dev_kernel, dim3(grid), dim3(BIN_T), (size_t)tiles * 4, s, db, tiles);
+    hipLaunchKernelGGL(bin_row_scan_dev_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, db, tiles);
+    hipLaunchKernelGGL(bin_scatter_dev_kernel, dim3(grid), dim3(BIN_T), (size_t)tiles * 16, s, db, tiles, nbits, ranges);
+}
+
+void launch_tile_depth_sort_dev(const DevBin& db, int tiles, const uint2* ranges, int cap_class, int write_keys, hipStream_t s)
+{
+    if (tiles <= 0) return;
+    hipLaunchKernelGGL(tile_depth_sort_dev_kernel, dim3(tiles), dim3(256), (size_t)cap_class * 16, s, db, ranges, cap_class, write_keys);
 }
 
 int tile_sort_capacity(long long R, int tiles)

@@ -226,6 +226,20 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     uint8_t* hits = fa->hits;    /* written by phase 0: neither const nor restrict */
     uint8_t* hits4 = fa->hits4;
     float4* __restrict__ zero = fa->zero;
+    uint64_t* sort_keys = fa->keys; uint64_t* sort_keys_alt = fa->keys_alt; uint32_t* sort_vals_alt = fa->vals_alt;
+    uint32_t* sort_list = fa->point_list;
+    if (fa->dev.base != nullptr) {
+        // launched before the host knew num_rendered (DevBin, gs2d_common.h): the count is on the device, the binning chunk's
+        // arrays follow from it (scalar loads and a little scalar arithmetic).  A count beyond the chunk's capacity: nothing
+        // is touched -- the host sees the same number and runs the stages again, in stream order, in a chunk that fits.
+        const uint32_t Rd = *fa->dev.R_dev;
+        if (Rd > fa->dev.cap) return;
+        const BinLayout BL = bin_layout((int)Rd, fa->dev.det != 0, (int)fa->dev.cap);
+        char* bb = fa->dev.base;
+        sort_list = (uint32_t*)(bb + BL.point_list); point_list = sort_list;
+        hits = (uint8_t*)(bb + BL.hits); hits4 = (uint8_t*)(bb + BL.hits4);
+        sort_keys = (uint64_t*)(bb + BL.keys); sort_keys_alt = (uint64_t*)(bb + BL.keys_alt); sort_vals_alt = (uint32_t*)(bb + BL.vals_alt);
+    }
     const int tile = xcd_tile(local_block, ntiles);
     if (tile < 0) { clear_share(zero, zero_n, local_block, blocks_per_frame); return; }
     // phase -1 (sort_cap > 0): this tile's list, binned by the counting sort in Gaussian order, is sorted by depth here --
@@ -234,8 +248,8 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     // point_list in global memory (the backward and the cull phase read them); workgroup scope is enough for the waves of
     // this workgroup to see them (see phase 0).
     if (sort_cap > 0) {
-        tile_depth_sort_body(tile, dyn_lds, reinterpret_cast<uint32_t (*)[256]>(dyn_lds + 4 * sort_cap), fa->ranges, fa->keys,
-                             fa->point_list, fa->keys_alt, fa->vals_alt, sort_cap, /*packed=*/1, write_keys);
+        tile_depth_sort_body(tile, dyn_lds, reinterpret_cast<uint32_t (*)[256]>(dyn_lds + 4 * sort_cap), fa->ranges, sort_keys,
+                             sort_list, sort_keys_alt, sort_vals_alt, sort_cap, /*packed=*/1, write_keys);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

@@ -27,7 +27,7 @@
 // Pixel-state planes kept between forward and backward (element index = tile*256 + thread).
 enum { PS_TFINAL = 0, PS_M1, PS_M2, PS_MEDIAN, PS_STD, PS_LAST, PS_MEDC, PS_PLANES };
 
-static inline size_t gs2d_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+__host__ __device__ static inline size_t gs2d_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct GeomLayout {
     size_t depths, tiles_touched, point_offsets, rec, clamped, scan_tmp, grad_rec, rect, total;
@@ -74,7 +74,8 @@ static inline GeomLayout geom_layout(int P)
 // (gs2d_api.hip, fwd_phase_b), into a chunk sized for C instances, so their offsets must not depend on R.  C < 0: C = R, the
 // layout a caller who knows R computes (gs2d_binning_bytes; the backward, which never touches the two arrays).
 // det: also room for the deterministic backward (inverse permutation + one partial gradient record per (instance, quadrant))
-static inline BinLayout bin_layout(int R, bool det = false, int C = -1)
+// (__host__ __device__: the kernels of the forward that run before the host knows R evaluate the layout themselves, DevBin below)
+__host__ __device__ static inline BinLayout bin_layout(int R, bool det = false, int C = -1)
 {
     BinLayout L;
     const size_t r = (size_t)(R > 0 ? R : 1);
@@ -215,9 +216,10 @@ void launch_inclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* t
 //  * scanned != 0: block_sums already holds exclusive block offsets (launch_offsets_blocksums, which also publishes the total):
 //    the path of callers that must know the total before they can place the output.
 void launch_offsets_blocksums(int P, uint32_t* block_sums, uint32_t* total_dev, uint32_t* total_host, hipStream_t s);
+// total_dev (optional): device word that receives the total as well (for the kernels behind it, DevBin)
 void launch_duplicate(int P, const ushort4* rect, const float* depths, const uint32_t* tiles_touched,
                       const uint32_t* block_sums, int scanned, uint32_t* point_offsets, int gx, uint64_t* keys, uint32_t* vals,
-                      uint32_t capacity, uint32_t* total_host, hipStream_t s);
+                      uint32_t capacity, uint32_t* total_host, hipStream_t s, uint32_t* total_dev = nullptr);
 // stable LSD radix sort of (u64 key, u32 val) pairs on key bits [begin_bit, end_bit). Result lands in keys_a/vals_a;
 // the unsorted input must sit in the "b" buffers when the pass count ceil((end-begin)/8) is odd, else in "a".
 void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int begin_bit,
@@ -225,6 +227,22 @@ void launch_sort_pairs(int R, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys
 // single-pass stable counting sort of the pairs by tile id (key >> 32) that also writes the tile ranges; the output is
 // PACKED: keys_out[i] = id << 32 | depth bits (vals_out untouched);
 // returns false (nothing launched) when there are more than GS2D_BIN_MAX_TILES tiles
+// The binning chunk as the kernels see it while the HOST does not know num_rendered yet (gs2d_api.hip, "forward without a host
+// reaction"): its base address, the device word duplicate_kernel's last workgroup stored the count in, the capacity C the chunk
+// was sized for and the mode.  A kernel reads R = *R_dev, does NOTHING when R > cap (the guess was too small: the offsets of the
+// layout would leave the chunk; the host notices the same number a little later and runs the stages again in a chunk of the right
+// size, in stream order, before anybody can read an output), and otherwise derives its pointers from bin_layout(R, det, cap) --
+// the very layout the backward computes from the R the host knows by then.
+struct DevBin {
+    char* base;
+    const uint32_t* R_dev;
+    uint32_t cap;
+    int det;
+};
+// launch_bin_by_tile with the count read on the device: grids sized for `cap` instances, surplus workgroups leave at once
+void launch_bin_by_tile_dev(const DevBin& db, int tiles, int nbits, uint2* ranges, hipStream_t s);
+// launch_tile_depth_sort (packed pairs) with the count read on the device; cap_class: the LDS capacity class to use
+void launch_tile_depth_sort_dev(const DevBin& db, int tiles, const uint2* ranges, int cap_class, int write_keys, hipStream_t s);
 bool launch_bin_by_tile(int R, int tiles, int nbits, const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out,
                         uint32_t* vals_out, uint32_t* hist, uint2* ranges, hipStream_t s);
 // one workgroup per tile: stable sort of the tile's segment by the 32 depth bits, in LDS.  packed: the segment holds
@@ -285,6 +303,8 @@ struct BlendFwdFrame {
     uint8_t* hits; uint8_t* hits4;  // written by phase 0 (cull bits, gs2d_cull.h)
     float4* zero;                   // the backward's gradient accumulator, cleared with the kernel's idle store slots
     uint64_t* keys; uint64_t* keys_alt; uint32_t* vals_alt;  // sort_cap > 0: the binned (depth, id) pairs of the tile lists + scratch
+    DevBin dev;                     // dev.base != nullptr: point_list, hits, hits4, keys, keys_alt, vals_alt are derived from it
+                                    // in the kernel (the host did not know num_rendered when it launched)
 };
 struct BlendFwdBatch { BlendFwdFrame f[GS2D_MAX_BATCH]; };
 struct BlendBwdFrame {

@@ -383,6 +383,16 @@ def is_reference_binning():
     return bool(_lib.lib().gs2d_get_reference_binning())
 
 
+def set_launch_ahead(on=True):
+    """gs2d_set_launch_ahead (default on): the forward enqueues all its kernels before the host reads num_rendered (the
+    stages behind the duplication read the count on the device); off = duplicate, host wait, the rest.  Process-wide."""
+    _lib.lib().gs2d_set_launch_ahead(int(bool(on)))
+
+
+def is_launch_ahead():
+    return bool(_lib.lib().gs2d_get_launch_ahead())
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     """_C.mark_visible (rasterize_points.cu:241-260)."""
     L = _lib.lib()

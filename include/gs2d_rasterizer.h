@@ -253,6 +253,16 @@ int gs2d_get_deterministic(void);
  * bit-identical to the reference's (what the binning parity tests compare against the oracle).
  */
 void gs2d_set_reference_binning(int on);
+/* Launch-ahead forward (default on): a single-frame forward enqueues ALL its kernels before the host looks at num_rendered --
+ * the stages behind the instance duplication read the count on the device, their grids are sized for the capacity of the
+ * binning chunk (requested from the previous call's count for the same problem shape, + 12.5 %), and the one host read of the
+ * reference's forward (rasterizer_impl.cu:287) happens after the blend kernel is enqueued, when the GPU's queue is full.
+ * A count beyond the capacity (first call of a shape, a scene that grew by more than 12.5 % between calls) makes those
+ * kernels do nothing and the host run the stages again in a chunk of the exact size, in stream order: results never differ.
+ * 0 restores the round-3 order (duplicate, host wait, the rest); debug mode, the deterministic mode, batches and images of
+ * more than 4096 tiles always use that order.  Process-wide. */
+void gs2d_set_launch_ahead(int on);
+int gs2d_get_launch_ahead(void);
 int gs2d_get_reference_binning(void);
 
 /* present: [P] bytes (0/1). */

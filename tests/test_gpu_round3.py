@@ -414,8 +414,12 @@ def _grow_scene(P, W, H, seed, scale_hi):
     return make_scene(P, W, H, seed=seed, regime="mapping", scale_lo=0.3, scale_hi=scale_hi)
 
 
-def test_duplicate_before_num_rendered_guess_too_small_and_large_enough(oracle):
-    """duplicate_kernel runs before the host knows num_rendered, into a binning chunk sized from the previous call of the same
+@pytest.mark.parametrize("ahead", [True, False])
+def test_duplicate_before_num_rendered_guess_too_small_and_large_enough(oracle, ahead):
+    """ahead=True (the default, gs2d_set_launch_ahead): ALL kernels of the forward are enqueued before the host looks at
+    num_rendered; the stages behind duplicate read the count on the device and do nothing when it exceeds the chunk's capacity,
+    the host then runs them again in a chunk that fits.  ahead=False: the round-3 order.  Either way:
+    duplicate_kernel runs before the host knows num_rendered, into a binning chunk sized from the previous call of the same
     problem shape (+12.5 %), and sends the total to the host from its last workgroup (gs2d_api.hip, fwd_phase_b).  Same shape,
     growing and shrinking scenes: a call whose guess was too small (second launch into an exact-size chunk) and a call whose
     guess was generous give the lists, ranges and images of the oracle, bit for bit, and their gradients agree with a call
@@ -426,10 +430,17 @@ def test_duplicate_before_num_rendered_guess_too_small_and_large_enough(oracle):
     assert o_big["num_rendered"] > 1.125 * o_small["num_rendered"] + 4096 > 0  # the small scene's count is too small a guess
     dc, da = util.make_upstream_grads(W, H, channels=(0, 1, 5, 6))
     dc, da = (dc * W * H).numpy(), (da * W * H).numpy()
+    from gaus_slam_amd import rasterizer
+    assert rasterizer.is_launch_ahead()  # the library default
+    rasterizer.set_launch_ahead(ahead)
     grads = {}
-    for name, sc, o in (("small", small, o_small), ("big after small: guess too small", big, o_big), ("big after big: fits", big, o_big),
-                        ("small after big: generous", small, o_small)):
-        h = util.hip_forward(sc, use_sa=True)
+    try:
+        hs = [(name, o, util.hip_forward(sc, use_sa=True))
+              for name, sc, o in (("small", small, o_small), ("big after small: guess too small", big, o_big),
+                                  ("big after big: fits", big, o_big), ("small after big: generous", small, o_small))]
+    finally:
+        rasterizer.set_launch_ahead(True)
+    for name, o, h in hs:
         assert h["num_rendered"] == o["num_rendered"], name
         np.testing.assert_array_equal(h["point_list"], o["point_list"], err_msg=name)
         np.testing.assert_array_equal(h["ranges"], o["ranges"], err_msg=name)
