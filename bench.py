@@ -157,6 +157,11 @@ def main():
     else:
         result = op_workload(args, dev, P, W, H, regime, use_sa, rank, world)
     if rank == 0 and result is not None:
+        # which kernels produced this number: the hash compiled into the loaded library and the hash of the tree's sources
+        # (equal unless GS2D_LIB_PATH points at an experiment build); tests/test_host.py holds the kept artifacts to it
+        from gaus_slam_amd import build as _gs_build
+        result["build"] = {"source_hash": _lib.lib_source_hash(), "tree_source_hash": _gs_build.source_hash(),
+                           "info": _lib.build_info()}
         line = json.dumps(result)
         sys.stdout.flush()
         os.write(json_fd, (line + "\n").encode())
@@ -240,6 +245,74 @@ def timed(one_step, steps, warmup, world, dev, prewarm=True):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
+
+
+def build_roofline(args, dev, stage_ms, P, R, HW, ms_per_step, pose_only=False):
+    """The `roofline` object of the JSON line: dominant kernel (by the hipEvent stage times recorded on the launch stream),
+    its algorithmic bytes against the HBM peak as the bench contract asks, HBM traffic and VALU instruction counts from the
+    committed rocprofv3 PMC summary of the same command (profiles/pmc_traffic[_<workload>]_rNN.json, pmc_valu...)."""
+    sb = stage_bytes(P, R, HW)
+    if pose_only:  # tracking: the backward keeps 16 B per Gaussian (dense dT[2], dT[5], dT[8]) instead of the 72-B write-back
+        sb["blend_bwd"] = 84 * R + 68 * HW + 16 * P
+        sb["preprocess_bwd"] = 40 * P
+    dom = max(("blend_fwd", "blend_bwd", "sort", "preprocess", "preprocess_bwd"), key=lambda n: stage_ms[n])
+    achieved = sb[dom] / (stage_ms[dom] * 1e-3) / 1e9
+    W0, H0, P0, _ = WORKLOADS[args.workload]
+    default_shape = not (args.gaussians or args.width or args.height) and (P0 * HW > 0)
+    suffix = "" if args.workload == "op" else "_" + args.workload
+    traffic, traffic_source = None, None
+    tpath = latest_profile("pmc_traffic" + suffix)
+    if tpath and default_shape:
+        try:
+            traffic = json.load(open(tpath)).get(dom)
+            traffic_source = (f"{os.path.relpath(tpath, ROOT)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                              "committed with the kernels; not measured in this run")
+        except Exception:
+            traffic = None
+    # measured streaming bandwidth of this box (1 GiB device-to-device copy), quoted beside the 8 TB/s spec peak
+    x = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    for _ in range(2):
+        y.copy_(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        y.copy_(x)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * x.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del x, y
+    # The ceiling the dominant kernel actually runs against: vector-instruction issue.  Instruction counts come from the
+    # committed rocprofv3 PMC profile of this command, the peak from the kept microbenchmark output (see VALU_PEAK_GINST).
+    valu = None
+    vpath = latest_profile("pmc_valu" + suffix)
+    if vpath and default_shape:
+        try:
+            vi = json.load(open(vpath)).get(dom)
+            ach = vi["valu_wave_insts"] / (stage_ms[dom] * 1e-3) / 1e9
+            valu = {"kernel": dom, "achieved_Gwaveinst_s": round(ach, 1), "peak_Gwaveinst_s": round(VALU_PEAK_GINST, 1),
+                    "frac": round(ach / VALU_PEAK_GINST, 3), "nominal_peak_Gwaveinst_s": round(VALU_NOMINAL_GINST, 1),
+                    "frac_nominal": round(ach / VALU_NOMINAL_GINST, 3), "valu_wave_insts": vi["valu_wave_insts"],
+                    "salu_wave_insts": vi.get("salu_wave_insts"),
+                    "source": f"{os.path.relpath(vpath, ROOT)} (SQ_INSTS_VALU of the committed PMC profile); peak from "
+                              "profiles/issue_bench_r02.txt, profiles/select_bench_r02.txt"}
+        except Exception:
+            valu = None
+    closest = "valu-issue" if valu and valu["frac"] > achieved / HBM_PEAK_GBS else "hbm"
+    frame_bytes = sum(sb[k] for k in ("preprocess", "scan", "duplicate", "sort", "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd")) if pose_only \
+        else 492 * P + 196 * R + 136 * HW
+    return {"bound": "valu" if closest == "valu-issue" else "hbm",
+            "bound_note": "achieved / peak / frac below price the kernel against the HBM peak, as the bench contract asks for every "
+                          "kernel; the ceiling it actually runs against is in valu_ceiling (frac = against the measured issue "
+                          "rate, frac_nominal = against the guide's 2-cycle rate)",
+            "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+            "closest_ceiling": closest,
+            "measured_copy_GBps": round(copy_gbs, 1), "valu_ceiling": valu,
+            "kernel_ms": round(stage_ms[dom], 4),
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "frame_algorithmic_bytes": frame_bytes,
+            "frame_frac_of_hbm_peak": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
 
 def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
@@ -390,61 +463,7 @@ def op_workload(args, dev, P, W, H, regime, use_sa, rank, world):
             R_ref = count()  # instances of the reference's 3-sigma rectangles, for comparison only
         finally:
             rasterizer.set_reference_binning(False)
-    sb = stage_bytes(P, R, H * W)
-    dom = max(("blend_fwd", "blend_bwd", "sort", "preprocess", "preprocess_bwd"), key=lambda n: stage_ms[n])
-    achieved = sb[dom] / (stage_ms[dom] * 1e-3) / 1e9
-    headline = (P, W, H) == (500000, 640, 480)
-    traffic, traffic_source = None, None
-    tpath = latest_profile("pmc_traffic")
-    if tpath and headline:
-        try:
-            traffic = json.load(open(tpath)).get(dom)
-            traffic_source = (f"{os.path.relpath(tpath, ROOT)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                              "committed with the kernels; not measured in this run")
-        except Exception:
-            traffic = None
-    # measured streaming bandwidth of this box (1 GiB device-to-device copy), quoted beside the 8 TB/s spec peak
-    x = torch.empty(1 << 28, dtype=torch.float32, device=dev)
-    y = torch.empty_like(x)
-    for _ in range(2):
-        y.copy_(x)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        y.copy_(x)
-    e1.record()
-    torch.cuda.synchronize()
-    copy_gbs = 5 * 2 * x.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del x, y
-    # The ceiling the dominant kernel actually runs against: vector-instruction issue.  Instruction counts come from the
-    # committed rocprofv3 PMC profile of this command, the peak from the kept microbenchmark output (see VALU_PEAK_GINST).
-    valu = None
-    vpath = latest_profile("pmc_valu")
-    if vpath and headline:
-        try:
-            vi = json.load(open(vpath)).get(dom)
-            ach = vi["valu_wave_insts"] / (stage_ms[dom] * 1e-3) / 1e9
-            valu = {"kernel": dom, "achieved_Gwaveinst_s": round(ach, 1), "peak_Gwaveinst_s": round(VALU_PEAK_GINST, 1),
-                    "frac": round(ach / VALU_PEAK_GINST, 3), "nominal_peak_Gwaveinst_s": round(VALU_NOMINAL_GINST, 1),
-                    "frac_nominal": round(ach / VALU_NOMINAL_GINST, 3), "valu_wave_insts": vi["valu_wave_insts"],
-                    "salu_wave_insts": vi.get("salu_wave_insts"),
-                    "source": f"{os.path.relpath(vpath, ROOT)} (SQ_INSTS_VALU of the committed PMC profile); peak from "
-                              "profiles/issue_bench_r02.txt, profiles/select_bench_r02.txt"}
-        except Exception:
-            valu = None
-    closest = "valu-issue" if valu and valu["frac"] > achieved / HBM_PEAK_GBS else "hbm"
-    roofline = {"bound": "valu" if closest == "valu-issue" else "hbm",
-                "bound_note": "achieved / peak / frac below price the kernel against the HBM peak, as the bench contract asks for every "
-                              "kernel; the ceiling it actually runs against is in valu_ceiling (frac = against the measured issue "
-                              "rate, frac_nominal = against the guide's 2-cycle rate)",
-                "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
-                "closest_ceiling": closest,
-                "measured_copy_GBps": round(copy_gbs, 1), "valu_ceiling": valu,
-                "kernel_ms": round(stage_ms[dom], 4),
-                "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-                "frame_algorithmic_bytes": 492 * P + 196 * R + 136 * H * W,
-                "frame_frac_of_hbm_peak": round((492 * P + 196 * R + 136 * H * W) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    roofline = build_roofline(args, dev, stage_ms, P, R, H * W, ms_per_step)
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
         cpu_baseline = cpu_baseline_leg(sc, W, H, use_sa)
@@ -553,13 +572,23 @@ def slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world):
             acc[i] += max(buf[i], 0.0)
     L.gs2d_stage_timing_enable(0)
     stage_ms = {n: round(acc[i] / 10, 4) for i, n in enumerate(STAGES)}
+    from gaus_slam_amd import rasterizer
+    with torch.no_grad():  # instances the iteration's render handles
+        e = torch.empty(0, device=dev)
+        q = p if args.workload == "tracking" else leaves
+        kw = dict(pose_Rt=w2c[:3, :4].detach().contiguous()) if args.workload == "tracking" else {}
+        R = rasterizer.rasterize_gaussians(settings.bg, q["means3D"], q["colors"], q["opacities"], q["scales"], q["rotations"], 1.0, e,
+                                           settings.viewmatrix, settings.projmatrix, settings.tanfovx, settings.tanfovy, H, W, e, 0,
+                                           settings.campos, use_sa, False, False, **kw)[0]
+    roofline = build_roofline(args, dev, stage_ms, sc["means3D"].shape[0], R, H * W, elapsed / args.steps * 1e3,
+                              pose_only=args.workload == "tracking")
     return {"metric": metric, "value": round(args.steps / elapsed, 3), "unit": "iterations/s", "n_gpus": 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {W}x{H} / {P} Gaussians, {args.workload} iteration (BASELINE.json configs[2] loop shape), "
                                    f"use_sa={use_sa}", "step": step_desc, "parallelism": "single GPU", "prewarm_steps": PREWARM_DONE,
-                       "stage_ms": stage_ms, "host_cpu_fraction": host_cpu},
-            "roofline": None, "cpu_baseline": None}
+                       "num_rendered": R, "stage_ms": stage_ms, "host_cpu_fraction": host_cpu},
+            "roofline": roofline, "cpu_baseline": None}
 
 
 def cpu_baseline_leg(sc, W, H, use_sa):

@@ -105,3 +105,14 @@ def lib():
 
 def last_error():
     return lib().gs2d_last_error().decode()
+
+
+def build_info():
+    """gs2d_build_info(): flags, build date and the hash of the kernel sources the loaded library was compiled from."""
+    return lib().gs2d_build_info().decode()
+
+
+def lib_source_hash():
+    """The source hash compiled into the loaded library ("unknown" for a library not built by gaus_slam_amd/build.py)."""
+    info = build_info()
+    return info.rsplit(" src ", 1)[1] if " src " in info else "unknown"

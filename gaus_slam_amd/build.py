@@ -19,10 +19,32 @@ SOURCES = ["gs2d_preprocess.hip", "gs2d_binning.hip", "gs2d_blend.hip", "gs2d_de
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17"]
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from: every file under csrc/ plus the C-ABI
+    header, in name order (name and content).  Compiled into the library (gs2d_build_info) and written into every JSON bench.py
+    emits, so that a kept artifact says which kernels produced it (tests/test_host.py checks the profiles of the current round)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.listdir(CSRC))
+    for f in files:
+        h.update(f.encode() + b"\0")
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(_HERE, "..", "include", "gs2d_rasterizer.h"), "rb") as fh:
+        h.update(b"gs2d_rasterizer.h\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def _stale():
     if os.environ.get("GS2D_LIB_PATH"):
         return False
     if not os.path.exists(LIB_PATH):
+        return True
+    try:  # the hash the library was built from (sidecar written by build())
+        with open(LIB_PATH + ".hash") as fh:
+            if fh.read().strip() != source_hash():
+                return True
+    except OSError:
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "gs2d_rasterizer.h")]
@@ -35,10 +57,13 @@ def build(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    cmd = [hipcc] + FLAGS + ["-o", LIB_PATH] + srcs
+    sh = source_hash()
+    cmd = [hipcc] + FLAGS + [f'-DGS2D_SOURCE_HASH="{sh}"', "-o", LIB_PATH] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(LIB_PATH + ".hash", "w") as fh:
+        fh.write(sh + "\n")
     return LIB_PATH
 
 

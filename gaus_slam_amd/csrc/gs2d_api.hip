@@ -218,7 +218,10 @@ void gs2d_set_launch_ahead(int on) { g_launch_ahead.store(on != 0); }
 int gs2d_get_launch_ahead(void) { return g_launch_ahead.load(); }
 int gs2d_get_reference_binning(void) { return g_reference_binning.load(); }
 
-const char* gs2d_build_info(void) { return "gs2d-hip gfx950 strict-fp (fp-contract=off) " __DATE__; }
+#ifndef GS2D_SOURCE_HASH
+#define GS2D_SOURCE_HASH "unknown"   /* gaus_slam_amd/build.py passes the hash of csrc/ + the C-ABI header */
+#endif
+const char* gs2d_build_info(void) { return "gs2d-hip gfx950 strict-fp (fp-contract=off) " __DATE__ " src " GS2D_SOURCE_HASH; }
 
 size_t gs2d_geometry_bytes(int P) { return geom_layout(P).total; }
 size_t gs2d_image_bytes(int width, int height) { return img_layout(width, height).total; }

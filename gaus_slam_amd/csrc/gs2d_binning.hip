@@ -11,6 +11,8 @@
 #include "gs2d_scan.h"
 #include "gs2d_tile_sort.h"
 
+#include <stdlib.h>
+
 namespace {
 
 __global__ void __launch_bounds__(SCAN_T) scan_reduce_kernel(const uint32_t* __restrict__ in, int n, uint32_t* __restrict__ block_sums)
@@ -228,38 +230,47 @@ constexpr int BIN_T = 256;
 constexpr int BIN_ITEMS = GS2D_BIN_ITEMS;   // instances per workgroup
 constexpr int BIN_WAVE_ITEMS = BIN_ITEMS / 4;
 
-// hist[tile * nblocks + block]
+// hist[tile * nblocks + block].  ITEMS = instances per workgroup: BIN_ITEMS (4096) or a multiple of it.  Every workgroup
+// pays for the whole tile table (clearing, writing and later scanning `ntiles` counters), so with thousands of tiles a
+// 4096-pair workgroup spends more time on the table than on its pairs (ScanNet++ shape, 4015 tiles: 40 + 13 + 108 us for the
+// three passes): images of many tiles take larger workgroups (bin_items_for), a quarter of the counters and of the rows to scan.
+template <int ITEMS>
 __device__ __forceinline__ void
 bin_hist_body(const uint64_t* __restrict__ keys, int n, int ntiles, uint32_t* __restrict__ hist, int nblocks)
 {
     extern __shared__ uint32_t lds[];  // [ntiles]
     for (int t = threadIdx.x; t < ntiles; t += BIN_T) lds[t] = 0;
     __syncthreads();
-    const int base = blockIdx.x * BIN_ITEMS;
-    const int end = min(n, base + BIN_ITEMS);
-    // all loads in flight before the first LDS atomic: the kernel is latency-bound, not bandwidth-bound
-    uint32_t tl[BIN_ITEMS / BIN_T];
+#pragma unroll 1
+    for (int sub = 0; sub < ITEMS / BIN_ITEMS; sub++) {
+        const int base = blockIdx.x * ITEMS + sub * BIN_ITEMS;
+        const int end = min(n, base + BIN_ITEMS);
+        if (base >= end) break;
+        // all loads in flight before the first LDS atomic: the kernel is latency-bound, not bandwidth-bound
+        uint32_t tl[BIN_ITEMS / BIN_T];
 #pragma unroll
-    for (int r = 0; r < BIN_ITEMS / BIN_T; r++) {
-        const int i = base + r * BIN_T + threadIdx.x;
-        tl[r] = i < end ? (uint32_t)(keys[i] >> 32) : 0xffffffffu;
+        for (int r = 0; r < BIN_ITEMS / BIN_T; r++) {
+            const int i = base + r * BIN_T + threadIdx.x;
+            tl[r] = i < end ? (uint32_t)(keys[i] >> 32) : 0xffffffffu;
+        }
+#pragma unroll
+        for (int r = 0; r < BIN_ITEMS / BIN_T; r++)
+            if (tl[r] != 0xffffffffu) atomicAdd(&lds[tl[r]], 1u);
     }
-#pragma unroll
-    for (int r = 0; r < BIN_ITEMS / BIN_T; r++)
-        if (tl[r] != 0xffffffffu) atomicAdd(&lds[tl[r]], 1u);
     __syncthreads();
     for (int t = threadIdx.x; t < ntiles; t += BIN_T) hist[(size_t)t * nblocks + blockIdx.x] = lds[t];
 }
+template <int ITEMS>
 __global__ void __launch_bounds__(BIN_T)
 bin_hist_kernel(const uint64_t* __restrict__ keys, int n, int ntiles, uint32_t* __restrict__ hist, int nblocks)
 {
-    bin_hist_body(keys, n, ntiles, hist, nblocks);
+    bin_hist_body<ITEMS>(keys, n, ntiles, hist, nblocks);
 }
 __global__ void __launch_bounds__(BIN_T) bin_hist_batch_kernel(int ntiles, const gs2d::BinFrames tab)
 {
     const gs2d::BinFrame& f = tab.f[blockIdx.y];
     if ((int)blockIdx.x >= f.nblocks) return;  // the grid is sized for the frame with the most instances
-    bin_hist_body(f.keys_unsorted, f.R, ntiles, f.hist, f.nblocks);
+    bin_hist_body<BIN_ITEMS>(f.keys_unsorted, f.R, ntiles, f.hist, f.nblocks);
 }
 
 // hist[tile][0..nblocks) -> exclusive scan along the blocks, in place; tile_total[tile] = the row's sum.  One wave per tile.
@@ -293,6 +304,10 @@ __global__ void __launch_bounds__(256) bin_row_scan_batch_kernel(int ntiles, con
 // offs_excl[tile][block] = instances of the tile in earlier blocks (bin_row_scan_kernel), tile_total[tile] = all of them.
 // Stable: element order inside a tile is preserved.
 // Output: packed (depth bits, id) pairs in keys_out's 8-byte slots (vals_out is not written).
+// ITEMS == BIN_ITEMS: each wave's 1024 pairs stay in registers between the counting and the scatter; larger ITEMS (images of
+// many tiles, see bin_hist_body): each wave owns ITEMS / 4 CONSECUTIVE pairs (so that (wave, position) order is element
+// order, which stability needs), counts them in rounds of 1024 and reads them a second time (cache-warm) to scatter.
+template <int ITEMS>
 __device__ __forceinline__ void
 bin_scatter_body(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
                  uint32_t* __restrict__ vals_out, int n, int ntiles, int nbits, const uint32_t* __restrict__ offs_excl,
@@ -302,22 +317,31 @@ bin_scatter_body(const uint64_t* __restrict__ keys_in, const uint32_t* __restric
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int t = threadIdx.x; t < 4 * ntiles; t += BIN_T) lds[t] = 0;
     __syncthreads();
-    const int wbeg = blockIdx.x * BIN_ITEMS + wave * BIN_WAVE_ITEMS;
-    const int wend = min(n, wbeg + BIN_WAVE_ITEMS);
+    constexpr int WAVE_SPAN = ITEMS / 4;           // consecutive pairs per wave
+    constexpr int ROUNDS = WAVE_SPAN / BIN_WAVE_ITEMS;  // rounds of 1024
+    const int wbeg0 = blockIdx.x * ITEMS + wave * WAVE_SPAN;
+    const int wend0 = min(n, wbeg0 + WAVE_SPAN);
     uint32_t* mine = lds + wave * ntiles;
-    // the wave's 1024 pairs live in registers for the whole kernel (one round of loads, issued back to back)
     constexpr int PER_LANE = BIN_WAVE_ITEMS / 64;  // 16
     uint64_t k[PER_LANE];
     uint32_t v[PER_LANE];
+    int wbeg = wbeg0, wend = min(wend0, wbeg0 + BIN_WAVE_ITEMS);
+#pragma unroll 1
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        wbeg = wbeg0 + rd * BIN_WAVE_ITEMS;
+        wend = min(wend0, wbeg + BIN_WAVE_ITEMS);
+        if (rd > 0 && wbeg >= wend) break;
+        // one round of loads, issued back to back (ROUNDS == 1: the pairs stay in registers for the scatter below)
 #pragma unroll
-    for (int r = 0; r < PER_LANE; r++) {
-        const int i = wbeg + r * 64 + lane;
-        k[r] = i < wend ? keys_in[i] : ~0ull;
-        v[r] = i < wend ? vals_in[i] : 0u;
+        for (int r = 0; r < PER_LANE; r++) {
+            const int i = wbeg + r * 64 + lane;
+            k[r] = i < wend ? keys_in[i] : ~0ull;
+            if (ROUNDS == 1) v[r] = i < wend ? vals_in[i] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < PER_LANE; r++)
+            if (wbeg + r * 64 + lane < wend) atomicAdd(&mine[(uint32_t)(k[r] >> 32)], 1u);
     }
-#pragma unroll
-    for (int r = 0; r < PER_LANE; r++)
-        if (wbeg + r * 64 + lane < wend) atomicAdd(&mine[(uint32_t)(k[r] >> 32)], 1u);
     __syncthreads();
     {
         // tile bases = exclusive scan of the row totals: thread i owns the tiles [i K, (i+1) K), sums them, the 256 sums are
@@ -339,40 +363,55 @@ bin_scatter_body(const uint64_t* __restrict__ keys_in, const uint32_t* __restric
     }
     __syncthreads();
     const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll 1
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        if (ROUNDS > 1) {  // second look at this round's pairs (the counting pass brought them into the caches)
+            wbeg = wbeg0 + rd * BIN_WAVE_ITEMS;
+            wend = min(wend0, wbeg + BIN_WAVE_ITEMS);
+            if (wbeg >= wend) break;
 #pragma unroll
-    for (int r = 0; r < PER_LANE; r++) {
-        if (wbeg + r * 64 >= wend) break;  // wave-uniform
-        const bool valid = wbeg + r * 64 + lane < wend;
-        const uint32_t d = (uint32_t)(k[r] >> 32);
-        uint64_t peers = __ballot(valid);
-        for (int b = 0; b < nbits; b++) {
-            const uint64_t vote = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? vote : ~vote;
+            for (int r = 0; r < PER_LANE; r++) {
+                const int i = wbeg + r * 64 + lane;
+                k[r] = i < wend ? keys_in[i] : ~0ull;
+                v[r] = i < wend ? vals_in[i] : 0u;
+            }
         }
-        const uint32_t before = valid ? mine[d] : 0u;
-        __builtin_amdgcn_wave_barrier();
-        if (valid && (peers & lt_mask) == 0) mine[d] = before + (uint32_t)__popcll(peers);
-        __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            const uint32_t dst = before + (uint32_t)__popcll(peers & lt_mask);
-            // one 8-byte store per pair: (depth bits, Gaussian id); the tile id is implied by the position
-            reinterpret_cast<uint2*>(keys_out)[dst] = make_uint2((uint32_t)k[r], v[r]);
+#pragma unroll
+        for (int r = 0; r < PER_LANE; r++) {
+            if (wbeg + r * 64 >= wend) break;  // wave-uniform
+            const bool valid = wbeg + r * 64 + lane < wend;
+            const uint32_t d = (uint32_t)(k[r] >> 32);
+            uint64_t peers = __ballot(valid);
+            for (int b = 0; b < nbits; b++) {
+                const uint64_t vote = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? vote : ~vote;
+            }
+            const uint32_t before = valid ? mine[d] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && (peers & lt_mask) == 0) mine[d] = before + (uint32_t)__popcll(peers);
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                const uint32_t dst = before + (uint32_t)__popcll(peers & lt_mask);
+                // one 8-byte store per pair: (depth bits, Gaussian id); the tile id is implied by the position
+                reinterpret_cast<uint2*>(keys_out)[dst] = make_uint2((uint32_t)k[r], v[r]);
+            }
         }
     }
 }
+template <int ITEMS>
 __global__ void __launch_bounds__(BIN_T)
 bin_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
                    uint32_t* __restrict__ vals_out, int n, int ntiles, int nbits, const uint32_t* __restrict__ offs_excl,
                    const uint32_t* __restrict__ tile_total, int nblocks, uint2* __restrict__ ranges)
 {
-    bin_scatter_body(keys_in, vals_in, keys_out, vals_out, n, ntiles, nbits, offs_excl, tile_total, nblocks, ranges);
+    bin_scatter_body<ITEMS>(keys_in, vals_in, keys_out, vals_out, n, ntiles, nbits, offs_excl, tile_total, nblocks, ranges);
 }
 __global__ void __launch_bounds__(BIN_T) bin_scatter_batch_kernel(int ntiles, int nbits, const gs2d::BinFrames tab)
 {
     const gs2d::BinFrame& f = tab.f[blockIdx.y];
     if ((int)blockIdx.x >= f.nblocks) return;
-    bin_scatter_body(f.keys_unsorted, f.vals_unsorted, f.keys, f.point_list, f.R, ntiles, nbits, f.hist,
-                     f.hist + (size_t)ntiles * f.nblocks, f.nblocks, f.ranges);
+    bin_scatter_body<BIN_ITEMS>(f.keys_unsorted, f.vals_unsorted, f.keys, f.point_list, f.R, ntiles, nbits, f.hist,
+                                f.hist + (size_t)ntiles * f.nblocks, f.nblocks, f.ranges);
 }
 
 // The single-frame kernels with the count read on the device (DevBin, gs2d_common.h): same bodies, pointers from the layout of
@@ -382,38 +421,40 @@ struct DevBinPtrs {
     const uint64_t* keys_unsorted; const uint32_t* vals_unsorted;
     uint64_t* keys; uint32_t* point_list; uint64_t* keys_alt; uint32_t* vals_alt; uint32_t* hist;
 };
-__device__ __forceinline__ bool dev_bin_ptrs(const gs2d::DevBin& db, DevBinPtrs* o)
+__device__ __forceinline__ bool dev_bin_ptrs(const gs2d::DevBin& db, DevBinPtrs* o, int items)
 {
     const uint32_t R = *db.R_dev;
     if (R > db.cap) return false;
     const BinLayout L = bin_layout((int)R, db.det != 0, (int)db.cap);
     o->R = (int)R;
-    o->nblocks = ((int)R + BIN_ITEMS - 1) / BIN_ITEMS;
+    o->nblocks = ((int)R + items - 1) / items;
     o->keys = (uint64_t*)(db.base + L.keys); o->point_list = (uint32_t*)(db.base + L.point_list);
     o->keys_alt = (uint64_t*)(db.base + L.keys_alt); o->vals_alt = (uint32_t*)(db.base + L.vals_alt);
     o->keys_unsorted = o->keys_alt; o->vals_unsorted = o->vals_alt;  // one pass: the unsorted pairs sit in the "alt" buffers
     o->hist = (uint32_t*)(db.base + L.hist);
     return true;
 }
+template <int ITEMS>
 __global__ void __launch_bounds__(BIN_T) bin_hist_dev_kernel(const gs2d::DevBin db, int ntiles)
 {
     DevBinPtrs p;
-    if (!dev_bin_ptrs(db, &p) || (int)blockIdx.x >= p.nblocks) return;
-    bin_hist_body(p.keys_unsorted, p.R, ntiles, p.hist, p.nblocks);
+    if (!dev_bin_ptrs(db, &p, ITEMS) || (int)blockIdx.x >= p.nblocks) return;
+    bin_hist_body<ITEMS>(p.keys_unsorted, p.R, ntiles, p.hist, p.nblocks);
 }
-__global__ void __launch_bounds__(256) bin_row_scan_dev_kernel(const gs2d::DevBin db, int ntiles)
+__global__ void __launch_bounds__(256) bin_row_scan_dev_kernel(const gs2d::DevBin db, int ntiles, int items)
 {
     DevBinPtrs p;
-    if (!dev_bin_ptrs(db, &p)) return;
+    if (!dev_bin_ptrs(db, &p, items)) return;
     bin_row_scan_body(p.hist, ntiles, p.nblocks, p.hist + (size_t)ntiles * p.nblocks);  // (no instances: every row total is 0)
 }
+template <int ITEMS>
 __global__ void __launch_bounds__(BIN_T) bin_scatter_dev_kernel(const gs2d::DevBin db, int ntiles, int nbits, uint2* __restrict__ ranges)
 {
     DevBinPtrs p;
-    if (!dev_bin_ptrs(db, &p)) return;
+    if (!dev_bin_ptrs(db, &p, ITEMS)) return;
     // workgroup 0 always runs: it writes the tile ranges (all empty when there are no instances)
     if ((int)blockIdx.x >= p.nblocks && blockIdx.x != 0) return;
-    bin_scatter_body(p.keys_unsorted, p.vals_unsorted, p.keys, p.point_list, p.R, ntiles, nbits, p.hist,
+    bin_scatter_body<ITEMS>(p.keys_unsorted, p.vals_unsorted, p.keys, p.point_list, p.R, ntiles, nbits, p.hist,
                      p.hist + (size_t)ntiles * p.nblocks, p.nblocks, ranges);
 }
 __global__ void __launch_bounds__(256)
@@ -422,7 +463,7 @@ tile_depth_sort_dev_kernel(const gs2d::DevBin db, const uint2* __restrict__ rang
     extern __shared__ uint32_t dyn[];
     __shared__ uint32_t wcnt[4][256];
     DevBinPtrs p;
-    if (!dev_bin_ptrs(db, &p) || p.R == 0) return;
+    if (!dev_bin_ptrs(db, &p, BIN_ITEMS) || p.R == 0) return;
     tile_depth_sort_body(blockIdx.x, dyn, wcnt, ranges, p.keys, p.point_list, p.keys_alt, p.vals_alt, cap, 1, write_keys);
 }
 
@@ -459,6 +500,26 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t*
 }  // namespace
 
 namespace gs2d {
+
+// Instances per binning workgroup.  Every workgroup clears, writes and reads a whole tile table, so its share of pairs should
+// be a few times the number of tiles -- but the launch should still fill the chip.  count: the number of instances (or the
+// capacity of the chunk when the host does not know it yet); the three kernels of one pass must be given the same value.
+int bin_items_for(long long count, int tiles)
+{
+    static const int forced = [] { const char* e = getenv("GS2D_BIN_ITEMS_FORCE"); return e ? atoi(e) : 0; }();
+    if (forced == 4096 || forced == 8192 || forced == 16384) return forced;
+    if (tiles <= 1536) return BIN_ITEMS;
+    if (count >= 16384LL * 200) return 16384;
+    if (count >= 8192LL * 200) return 8192;
+    return BIN_ITEMS;
+}
+
+#define GS2D_BIN_DISPATCH(ITEMS_, ...)                          \
+    switch (ITEMS_) {                                          \
+    case 16384: { constexpr int I = 16384; __VA_ARGS__; } break; \
+    case 8192: { constexpr int I = 8192; __VA_ARGS__; } break;   \
+    default: { constexpr int I = BIN_ITEMS; __VA_ARGS__; } break; \
+    }
 
 void launch_inclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* tmp, uint32_t* total_out, hipStream_t s,
                            uint32_t* total_host)
@@ -510,23 +571,25 @@ bool launch_bin_by_tile(int R, int tiles, int nbits, const uint64_t* keys_in, co
                         uint32_t* vals_out, uint32_t* hist, uint2* ranges, hipStream_t s)
 {
     if (tiles > GS2D_BIN_MAX_TILES) return false;  // caller falls back to the 8-bit passes + tile_ranges kernel
-    const int nblocks = (R + BIN_ITEMS - 1) / BIN_ITEMS;
+    const int items = bin_items_for(R, tiles);
+    const int nblocks = (R + items - 1) / items;
     const size_t hist_elems = (size_t)tiles * nblocks;
     uint32_t* tile_total = hist + hist_elems;  // GS2D_BIN_MAX_TILES words behind the counters (bin_layout)
-    hipLaunchKernelGGL(bin_hist_kernel, dim3(nblocks), dim3(BIN_T), (size_t)tiles * 4, s, keys_in, R, tiles, hist, nblocks);
+    GS2D_BIN_DISPATCH(items, hipLaunchKernelGGL((bin_hist_kernel<I>), dim3(nblocks), dim3(BIN_T), (size_t)tiles * 4, s, keys_in, R, tiles, hist, nblocks));
     hipLaunchKernelGGL(bin_row_scan_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, hist, tiles, nblocks, tile_total);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblocks), dim3(BIN_T), (size_t)tiles * 16, s, keys_in, vals_in, keys_out, vals_out,
-                       R, tiles, nbits, hist, tile_total, nblocks, ranges);
+    GS2D_BIN_DISPATCH(items, hipLaunchKernelGGL((bin_scatter_kernel<I>), dim3(nblocks), dim3(BIN_T), (size_t)tiles * 16, s, keys_in, vals_in, keys_out,
+                                                vals_out, R, tiles, nbits, hist, tile_total, nblocks, ranges));
     return true;
 }
 
 void launch_bin_by_tile_dev(const DevBin& db, int tiles, int nbits, uint2* ranges, hipStream_t s)
 {
-    int grid = ((int)db.cap + BIN_ITEMS - 1) / BIN_ITEMS;
+    const int items = bin_items_for((long long)db.cap, tiles);
+    int grid = ((int)db.cap + items - 1) / items;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(bin_hist_dev_kernel, dim3(grid), dim3(BIN_T), (size_t)tiles * 4, s, db, tiles);
-    hipLaunchKernelGGL(bin_row_scan_dev_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, db, tiles);
-    hipLaunchKernelGGL(bin_scatter_dev_kernel, dim3(grid), dim3(BIN_T), (size_t)tiles * 16, s, db, tiles, nbits, ranges);
+    GS2D_BIN_DISPATCH(items, hipLaunchKernelGGL((bin_hist_dev_kernel<I>), dim3(grid), dim3(BIN_T), (size_t)tiles * 4, s, db, tiles));
+    hipLaunchKernelGGL(bin_row_scan_dev_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, db, tiles, items);
+    GS2D_BIN_DISPATCH(items, hipLaunchKernelGGL((bin_scatter_dev_kernel<I>), dim3(grid), dim3(BIN_T), (size_t)tiles * 16, s, db, tiles, nbits, ranges));
 }
 
 void launch_tile_depth_sort_dev(const DevBin& db, int tiles, const uint2* ranges, int cap_class, int write_keys, hipStream_t s)

@@ -7,21 +7,29 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 d = sys.argv[1]
 STAGE = {"blend_fwd_kernel": "blend_fwd", "blend_bwd_kernel": "blend_bwd", "preprocess_fwd_kernel": "preprocess",
-         "preprocess_bwd_kernel": "preprocess_bwd", "bin_hist_kernel": "sort", "bin_row_scan_kernel": "sort", "bin_scatter_kernel": "sort", "tile_depth_sort_kernel": "sort",
+         "preprocess_bwd_kernel": "preprocess_bwd", "preprocess_bwd_pose_kernel": "preprocess_bwd",
+         "bin_hist_kernel": "sort", "bin_row_scan_kernel": "sort", "bin_scatter_kernel": "sort", "tile_depth_sort_kernel": "sort",
+         "bin_hist_dev_kernel": "sort", "bin_row_scan_dev_kernel": "sort", "bin_scatter_dev_kernel": "sort", "tile_depth_sort_dev_kernel": "sort",
+         "radix_hist_kernel": "sort", "radix_scatter_kernel": "sort", "tile_ranges_kernel": "sort",
          "scan_reduce_kernel": "sort", "scan_apply_kernel": "sort", "duplicate_kernel": "duplicate"}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gaus_slam_amd import build as _gs_build  # noqa: E402  (the hash of the kernel sources these counters belong to)
+SOURCE_HASH = _gs_build.source_hash()
 
 
 def counters(sub):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            for k in STAGE:
-                if k in r["Kernel_Name"]:
-                    acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            m = re.search(r"::(\w+)\s*(?:<|\()", r["Kernel_Name"])  # "void (anonymous namespace)::blend_bwd_kernel<true, ...>(int, ..."
+            name = m.group(1) if m else ""
+            if name in STAGE:
+                acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
 
 
@@ -45,6 +53,8 @@ for k in ("blend_fwd_kernel", "blend_bwd_kernel"):
                            "kernel_cycles": int(sq2.get(k, {}).get("GRBM_GUI_ACTIVE", 0) / 8)}
 out_v["_note"] = ("rocprofv3 --pmc SQ_* passes of `bench.py --steps 3` (averages per launch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are "
                   "quad-cycles summed over waves; kernel_cycles = GRBM_GUI_ACTIVE / 8)")
+out_t["source_hash"] = SOURCE_HASH
+out_v["source_hash"] = SOURCE_HASH
 json.dump(out_t, open(os.path.join(d, "pmc_traffic.json"), "w"), indent=1)
 json.dump(out_v, open(os.path.join(d, "pmc_valu.json"), "w"), indent=1)
 print(json.dumps(out_t, indent=1))

@@ -13,11 +13,18 @@ d = sys.argv[1]
 
 
 def short(n):
-    for k in ("blend_fwd_kernel", "blend_bwd_kernel", "preprocess_fwd_kernel", "preprocess_bwd_kernel", "radix_hist_kernel",
-              "radix_scatter_kernel", "scan_reduce_kernel", "scan_blocksums_kernel", "scan_apply_kernel",
-              "duplicate_kernel", "tile_ranges_kernel", "tile_depth_sort_kernel", "bin_hist_kernel", "bin_row_scan_kernel", "bin_scatter_kernel", "sum_frames_kernel", "mark_visible_kernel", "knn_kernel",
-              "det_reduce_kernel", "det_inverse_kernel"):
+    for k in ("blend_fwd_kernel", "blend_bwd_kernel", "preprocess_fwd_kernel", "preprocess_bwd_pose_kernel", "preprocess_bwd_kernel",
+              "radix_hist_kernel", "radix_scatter_kernel", "scan_reduce_kernel", "scan_blocksums_kernel", "scan_apply_kernel",
+              "duplicate_kernel", "tile_ranges_kernel", "tile_depth_sort_dev_kernel", "tile_depth_sort_kernel", "bin_hist_dev_kernel",
+              "bin_row_scan_dev_kernel", "bin_scatter_dev_kernel", "bin_hist_kernel", "bin_row_scan_kernel", "bin_scatter_kernel",
+              "sum_frames_kernel", "mark_visible_kernel", "knn_kernel", "det_reduce_kernel", "det_inverse_kernel",
+              "slam_loss", "adam"):
         if k in n:
+            # the tracking backward runs the POSE instantiation of blend_bwd_kernel (fourth template argument true)
+            if k == "blend_bwd_kernel":
+                targs = n.split("blend_bwd_kernel<", 1)[1].split(">", 1)[0].replace(" ", "").split(",") if "blend_bwd_kernel<" in n else []
+                if len(targs) >= 4 and targs[3] == "true":
+                    return "blend_bwd_kernel<POSE>"
             return k
     return n.split("<")[0].split("(")[0][:60]
 
@@ -46,11 +53,12 @@ for k, v in sorted(tr.items(), key=lambda kv: -sum(kv[1])):
     print(f"{k:28s} {len(v):6d} {sum(v)/len(v):10.2f} {sum(v)/1e3:10.3f}  {100*sum(v)/tot:5.1f}%")
 fe, wr = counter("pmc_fetch", "FETCH_SIZE"), counter("pmc_write", "WRITE_SIZE")
 out = {}
-print("\nHBM traffic per launch (KB as reported; FETCH_SIZE x2 = gfx950 correction for wide coalesced reads)")
+print("\nHBM traffic per launch (counters in KiB as reported; FETCH_SIZE x2 = gfx950 correction, 128-byte requests counted as 64; "
+      "total in MB = 1e6 bytes, the unit of bench.py's roofline.traffic)")
 for k in sorted(set(fe) | set(wr)):
     f = sum(fe[k]) / len(fe[k]) if fe.get(k) else 0.0
     w = sum(wr[k]) / len(wr[k]) if wr.get(k) else 0.0
-    print(f"{k:28s} FETCH_SIZE {f:12.1f} KB  WRITE_SIZE {w:12.1f} KB  corrected total {(2*f+w)/1024:10.2f} MB")
+    print(f"{k:28s} FETCH_SIZE {f:12.1f} KiB  WRITE_SIZE {w:12.1f} KiB  corrected total {(2*f+w)*1024/1e6:10.2f} MB")
     out[k] = {"fetch_kb_raw": f, "write_kb": w, "bytes_corrected": (2 * f + w) * 1024}
 json.dump({"kernel_avg_us": {k: sum(v) / len(v) for k, v in tr.items()}, "traffic": out},
           open(os.path.join(d, "summary.json"), "w"), indent=1)

@@ -181,3 +181,33 @@ def test_debug_mode_dumps_the_arguments_of_a_failing_call(tmp_path, monkeypatch)
                                rotations=torch.rand(P, 4))
     dump = torch.load(tmp_path / "snapshot_fw.dump", weights_only=True)
     assert torch.equal(dump[1], means) and dump[-1] is True
+
+
+def test_build_info_carries_the_source_hash(hiplib):
+    """gs2d_build_info() names the hash of the kernel sources the library was compiled from (gaus_slam_amd/build.py:
+    csrc/* + the C-ABI header); for the in-tree library that is the hash of the tree."""
+    from gaus_slam_amd import build, _lib
+    if os.environ.get("GS2D_LIB_PATH"):
+        pytest.skip("an experiment library is loaded")
+    h = build.source_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", h)
+    assert _lib.lib_source_hash() == h, (_lib.build_info(), h)
+
+
+def test_kept_artifacts_of_this_round_come_from_the_trees_kernels():
+    """VERDICT r3, hygiene: one build, one set of artifacts.  Every JSON kept under profiles/ for the current round (name
+    contains _r04) says which kernel sources produced it (bench.py's `build.source_hash`, the PMC summaries' `source_hash`),
+    and that hash is the hash of the sources in this tree -- a kernel change after the artifacts were taken fails here until
+    scripts/gpu_round4_artifacts.sh has run again."""
+    import glob
+    import json
+    from gaus_slam_amd import build
+    h = build.source_hash()
+    stale = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_r04*.json"))):
+        with open(path) as fh:
+            d = json.loads(fh.read().strip().splitlines()[-1])
+        got = (d.get("build") or {}).get("source_hash") or d.get("source_hash")
+        if got != h:
+            stale.append((os.path.basename(path), got))
+    assert not stale, f"artifacts not from the tree's kernels ({h}): {stale}"
