@@ -29,6 +29,11 @@ def _collective(group=None):
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) >= MIN_COLLECTIVE_WORLD
 
 
+
+def _rasterizer():
+    from . import rasterizer  # lazy: ba_shard's bucket logic is importable (and tested) without the HIP library
+    return rasterizer
+
 class GradBucket:
     """Flat [13*P] fp32 buffer; each field is a contiguous [P,k] view (SoA segments, so packing a gradient is one
     contiguous copy and the collective is one large message: xGMI is per-link bound, fewer/larger is better)."""
@@ -251,10 +256,23 @@ class KeyframeShardedBA:
         return self.bucket.views
 
     def _probe_overlap(self):
-        """The coalesced asynchronous collective is torch-internal API (dist._coalescing_manager).  Try it once, on scratch
-        rows, and let the ranks AGREE on the outcome (MAX all-reduce of a failure flag) before anyone changes its
-        collective pattern: if any rank's torch build rejects it, all ranks fall back together -- and permanently -- to one
-        all-reduce of the whole bucket after the backward."""
+        """The coalesced asynchronous collective is torch-internal API (dist._coalescing_manager).  Whether this torch build
+        HAS it is checked first without any communication (a rank whose build lacks it must not leave its peers inside a
+        collective it never joins); the ranks exchange that answer, and only if all have it is the coalesced form tried once
+        on scratch rows and the outcome agreed on again (MAX all-reduce of a failure flag) before anyone changes its collective
+        pattern.  What this cannot recover from: a rank-local failure INSIDE the coalesced collective itself (peers already
+        in it) -- that hangs or aborts like any mismatched collective would; it covers API absence and failures that are the
+        same on every rank."""
+        have = 1 if hasattr(dist, "_coalescing_manager") else 0
+        if _collective(self.group):
+            hv = torch.tensor([1 - have], dtype=torch.int32, device=self.bucket.flat.device)
+            dist.all_reduce(hv, op=dist.ReduceOp.MAX, group=self.group)
+            have = 1 - int(hv.item())
+        if not have:
+            import warnings
+            warnings.warn("overlapped chunk all-reduce unavailable (torch.distributed has no _coalescing_manager on some rank)")
+            self.overlap_chunks = 1
+            return
         failed = 0
         try:
             scratch = GradBucket(8, self.bucket.flat.device)
@@ -328,8 +346,10 @@ class KeyframeShardedBA:
                 return self._step_overlapped(mine[0], P)
         if not mine:
             self.bucket.flat.zero_()
-        elif self.batch_fn is not None and 1 < len(mine) <= MAX_BATCH_KEYFRAMES and self.params["means3D"].is_cuda:
+        elif (self.batch_fn is not None and 1 < len(mine) <= MAX_BATCH_KEYFRAMES and self.params["means3D"].is_cuda
+              and not _rasterizer().is_deterministic()):
             # one batched operator call for all of this rank's keyframes; frame 0's gradients land in the bucket itself
+            # (the batched backward has no deterministic variant: in deterministic mode the keyframes go one by one below)
             self.bucket.pack(self.local_backward(mine, self.bucket.views if self.direct_grads else None, fn=self.batch_fn))
         elif len(mine) > 1 and self.n_streams > 1 and self.params["means3D"].is_cuda:
             per_kf = self._multi_stream_grads(mine)

@@ -982,7 +982,8 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
                                     /*need_record=*/scale_modifier != 1.0f,
                                     // deterministic mode: per-workgroup partials in the geometry chunk's depth array (4 B
                                     // per Gaussian, dead once the forward's duplicate stage has run; 48 B per 256 Gaussians needed)
-                                    (live_det && pose_Rt) ? (float*)(geom_buffer + GL.depths) : nullptr, s);
+                                    // (the mode of the FORWARD, like everything else this backward decides by mode)
+                                    (det && pose_Rt) ? (float*)(geom_buffer + GL.depths) : nullptr, s);
         g_timer.end(ST_PREPROCESS_BWD, s);
         GS2D_STAGE("preprocess_bwd");
     }

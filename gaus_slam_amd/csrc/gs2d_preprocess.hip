@@ -727,8 +727,8 @@ preprocess_bwd_batch_kernel(int P, int D, int M, const float* __restrict__ means
                            f.dL_drot, nullptr, nullptr, pg);
 }
 
-// gs2d_backward_batch(accumulate = 1): frame 0's outputs += frame 1's + ... + frame K-1's, added in frame order (the sums K
-// separate backwards followed by tensor additions produce, bit for bit) -- one launch instead of 6 (K - 1) elementwise kernels
+// gs2d_backward_batch(accumulate = 1): frame 0's PARAMETER gradients += frame 1's + ... + frame K-1's, added in frame order (the
+// sums K separate backwards followed by tensor additions produce, bit for bit) -- one launch instead of 5 (K - 1) elementwise kernels
 __global__ void __launch_bounds__(256) sum_frames_kernel(int P, int K, int M, const gs2d::PreBwdFrames tab)
 {
     const int g = blockIdx.x * 256 + threadIdx.x;
@@ -743,7 +743,8 @@ __global__ void __launch_bounds__(256) sum_frames_kernel(int P, int K, int M, co
         }                                                                                                       \
         _Pragma("unroll") for (int i = 0; i < N; i++) tab.f[0].F[(size_t)g * N + i] = v[i];                     \
     }
-    GS2D_SUM_FIELD(dL_dmean2D, 3)
+    // (not dL_dmean2D: the screen-space gradient is a per-VIEW quantity -- the reference accumulates its norm view by view for
+    // densification, scene/Gaussians.py:58-62 -- so every frame keeps its own, frame 0 included)
     GS2D_SUM_FIELD(dL_dmean3D, 3)
     GS2D_SUM_FIELD(dL_dcolor, 3)
     GS2D_SUM_FIELD(dL_dopacity, 1)

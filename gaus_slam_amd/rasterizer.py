@@ -520,9 +520,15 @@ def _stacked_cameras(settings_list):
     settings objects (identity-keyed, the last 8 sets are kept): a BA loop renders the same keyframes step after step, and
     neither the three stack kernels nor a device-synchronising background comparison belong on its critical path."""
     key = tuple(settings_list)
+    # ... and by the VERSION of their camera tensors: a pose refined in place (rs.viewmatrix.copy_(...) during BA; the
+    # NamedTuple's fields cannot be rebound but their tensors can be written) bumps torch's version counter and misses
+    ver = tuple((rs.viewmatrix._version, rs.projmatrix._version, rs.campos._version, rs.viewmatrix.data_ptr(),
+                 rs.projmatrix.data_ptr(), rs.campos.data_ptr()) for rs in key)
     for ent in _CAMERA_STACKS:
-        if len(ent[0]) == len(key) and all(a is b for a, b in zip(ent[0], key)):
+        if len(ent[0]) == len(key) and all(a is b for a, b in zip(ent[0], key)) and ent[4] == ver:
             return ent[1], ent[2], ent[3]
+    _CAMERA_STACKS[:] = [ent for ent in _CAMERA_STACKS
+                         if not (len(ent[0]) == len(key) and all(a is b for a, b in zip(ent[0], key)))]  # stale entry of this set
     rs0 = key[0]
     for rs in key[1:]:
         same = (rs.image_height == rs0.image_height and rs.image_width == rs0.image_width and rs.use_sa == rs0.use_sa
@@ -533,7 +539,7 @@ def _stacked_cameras(settings_list):
     vms = torch.stack([rs.viewmatrix.reshape(16) for rs in key]).float().contiguous()
     pms = torch.stack([rs.projmatrix.reshape(16) for rs in key]).float().contiguous()
     cps = torch.stack([rs.campos.reshape(3) for rs in key]).float().contiguous()
-    _CAMERA_STACKS.append((key, vms, pms, cps))
+    _CAMERA_STACKS.append((key, vms, pms, cps, ver))
     if len(_CAMERA_STACKS) > 8:
         _CAMERA_STACKS.pop(0)
     return vms, pms, cps
@@ -544,7 +550,13 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
     K allmaps); the gradient of every input is the sum over the frames (added in frame order, as K separate calls accumulate)."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings_list):
+    def forward(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings_list, *means2D):
+        # means2D: ONE gradient carrier shared by all frames (its gradient is then the sum over the frames -- autograd's
+        # semantics for a leaf used K times) or K carriers, one per frame (each receives ITS view's screen-space gradient:
+        # what the reference's per-view densification statistics need, scene/Gaussians.py:58-62)
+        if len(means2D) not in (1, len(settings_list)):
+            raise RuntimeError("means2D: one tensor, or one per frame")
+        ctx.n_m2 = len(means2D)
         rs0 = settings_list[0]
         vms, pms, cps = _stacked_cameras(settings_list)
         Rs, color, depth, radii, geoms, bins, imgs = rasterize_gaussians_batch(
@@ -581,10 +593,18 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             [rs.tanfovx for rs in ctx.settings_list], [rs.tanfovy for rs in ctx.settings_list], grad_out_color, grad_depth, sh,
             rs0.sh_degree, cps, geoms, ctx.Rs, bins, imgs, rs0.use_sa, rs0.debug, grad_sink=sink, lean=True, accumulate=True)
         total = per[0]  # frame order: the same sums K separate backwards accumulate (one kernel, gs2d_backward_batch(accumulate))
-        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+        (_g_m2, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = total
-        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
-                grad_cov3Ds_precomp, None)
+        # the screen-space gradients stay per frame in the library (never summed by gs2d_backward_batch)
+        if ctx.n_m2 == K:
+            g_m2 = tuple(per[k][0] for k in range(K))
+        else:
+            acc = per[0][0].clone()
+            for k in range(1, K):
+                acc += per[k][0]
+            g_m2 = (acc,)
+        return (grad_means3D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, None) + g_m2
 
 
 def rasterize_gaussians_apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -645,7 +665,9 @@ class GaussianRasterizer(nn.Module):
 class GaussianRasterizerBatch(nn.Module):
     """GaussianRasterizer for K cameras of the same image size in one call (no counterpart in the reference; for BA ranks
     that hold several keyframes, gaus_slam_amd/ba_shard.py).  forward(...) takes the arguments of
-    GaussianRasterizer.forward and returns (colors: K tensors [3,H,W], radii [K,P], allmaps: K tensors [7,H,W])."""
+    GaussianRasterizer.forward and returns (colors: K tensors [3,H,W], radii [K,P], allmaps: K tensors [7,H,W]).
+    means2D: one gradient carrier (receives the SUM of the K views' screen-space gradients) or a list of K carriers (each
+    receives its own view's: what add_densification_stats needs per view, scene/Gaussians.py:58-62)."""
 
     def __init__(self, settings_list):
         super().__init__()
@@ -665,6 +687,7 @@ class GaussianRasterizerBatch(nn.Module):
         rotations = empty() if rotations is None else rotations
         cov3D_precomp = empty() if cov3D_precomp is None else cov3D_precomp
         K = len(self.settings_list)
-        out = _RasterizeGaussiansBatch.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                             cov3D_precomp, self.settings_list)
+        m2 = tuple(means2D) if isinstance(means2D, (list, tuple)) else (means2D,)
+        out = _RasterizeGaussiansBatch.apply(means3D, shs, colors_precomp, opacities, scales, rotations,
+                                             cov3D_precomp, self.settings_list, *m2)
         return out[1:1 + K], out[0], out[1 + K:]

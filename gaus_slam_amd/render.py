@@ -35,10 +35,15 @@ def render(settings, means3D, means2D, opacities, shs=None, colors_precomp=None,
 def render_batch(settings_list, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                  cov3D_precomp=None):
     """render() for K cameras of the same image size in one operator call (GaussianRasterizerBatch): a list of K packages
-    with the keys of render()."""
+    with the keys of render().
+    means2D: a LIST of K gradient carriers (one per view; package k holds means2D[k], whose .grad is that view's screen-space
+    gradient -- feed it to the reference's add_densification_stats(render_pkg) exactly like the package of a single render(),
+    slam/Backend.py:117-118, scene/Gaussians.py:58-62) or ONE tensor shared by all views: its .grad is then the SUM of the K
+    views' gradients (autograd's semantics for a leaf used K times) and must NOT be fed to per-view densification statistics."""
     color, radius, allmap = GaussianRasterizerBatch(settings_list)(
         means3D, means2D, opacities=opacities, shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
         cov3D_precomp=cov3D_precomp)
-    return [{"render_color": color[k], "radius": radius[k], "means2D": means2D, "allmap": allmap[k],
+    per_view = isinstance(means2D, (list, tuple))
+    return [{"render_color": color[k], "radius": radius[k], "means2D": means2D[k] if per_view else means2D, "allmap": allmap[k],
              "render_depth": allmap[k][0:1], "render_alpha": allmap[k][1:2], "render_normal": allmap[k][2:5],
              "render_middepth": allmap[k][5:6], "render_dist": allmap[k][6:7]} for k in range(len(settings_list))]

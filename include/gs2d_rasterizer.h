@@ -218,9 +218,11 @@ typedef struct gs2d_frame_grad {     /* per-frame arguments of gs2d_backward (sa
     float* dL_dmean2D; float* dL_dnormal; float* dL_dopacity; float* dL_dcolor; float* dL_dmean3D;
     float* dL_dtransMat; float* dL_dsh; float* dL_dscale; float* dL_drot;
 } gs2d_frame_grad;
-/* accumulate != 0: after the per-frame gradients have been written, frame 0's dL_* arrays receive the sum over all K frames
- * (added in frame order: the result K separate backwards followed by tensor additions give) -- what a BA rank needs; frames
- * 1 .. K-1 still hold their own gradients. */
+/* accumulate != 0: after the per-frame gradients have been written, frame 0's PARAMETER gradients (dL_dmean3D, dL_dcolor,
+ * dL_dopacity, dL_dscale, dL_drot, dL_dsh, dL_dnormal, dL_dtransMat) receive the sum over all K frames (added in frame order:
+ * the result K separate backwards followed by tensor additions give) -- what a BA rank needs; frames 1 .. K-1 still hold
+ * their own gradients.  dL_dmean2D is NEVER summed: the screen-space gradient is a per-view quantity (the reference
+ * accumulates its norm view by view for densification, scene/Gaussians.py:58-62), every frame keeps its own. */
 int gs2d_backward_batch(
     int K, const gs2d_frame_grad* frames, int accumulate, int P, int D, int M, const float* background, int width, int height,
     const float* means3D, const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
@@ -234,8 +236,9 @@ int gs2d_backward_batch(
  * bit-identical gradients (tests/test_gpu_round2.py).  Slower (about 2x for the backward) and 324 B more scratch per tile
  * instance.  The forward sizes the binning chunk for the mode it runs in and records that mode; a backward called with the
  * switch in the other position fails with an error (nothing is launched) -- restore the switch or rerun the forward.
- * Exception: the POSE gradient (dL_dpose of the *_posed / *_staged calls) is summed with 12 float atomics per workgroup in
- * either mode, so its last bits may still differ from run to run.
+ * The POSE gradient (dL_dpose of the *_posed / *_staged calls) is deterministic in this mode as well: one partial per workgroup
+ * of the per-Gaussian stage, summed in a fixed order by a reduction kernel (tests/test_gpu_round3.py); the partials are kept
+ * in the geometry chunk's `depths` array, which therefore no longer holds the view depths after a deterministic posed backward.
  */
 void gs2d_set_deterministic(int on);
 int gs2d_get_deterministic(void);

@@ -101,7 +101,10 @@ def test_batch_equals_separate_calls(K, P, W, H, use_sa):
         tot = g_acc[1][i].clone()          # frames 1..K-1 keep their own gradients: rebuild the sum from this same call
         for k in range(2, K):
             tot = tot + g_acc[k][i]
-        ref = g_bat[0][i].double() + sum(g_bat[k][i].double() for k in range(1, K))
+        if name == "means2D":  # the screen-space gradient is per view: never summed, frame 0 keeps its own
+            ref = g_bat[0][i].double()
+        else:
+            ref = g_bat[0][i].double() + sum(g_bat[k][i].double() for k in range(1, K))
         assert util.grad_err(g_acc[0][i].double().cpu().numpy(), ref.cpu().numpy()) <= 1e-5, name
     # a second batched backward on the same forward state (accumulators no longer known clean) gives the same result
     g_bat2 = rasterizer.rasterize_gaussians_backward_batch(
@@ -198,3 +201,130 @@ def test_batched_operator_and_ba_step_match_keyframe_by_keyframe():
         assert np.abs(res["seq"][n]).max() > 0
         assert util.grad_err(res["batch"][n], res["seq"][n]) <= 1e-5, n
         assert util.grad_err(res["batch_direct"][n], res["seq"][n]) <= 1e-5, n
+
+
+def test_batch_screen_space_gradients_stay_per_view():
+    """the reference's mapping step feeds every rendered view's means2D.grad to add_densification_stats
+    (slam/Backend.py:117-118; scene/Gaussians.py:58-62 accumulates norm(means2D.grad[:, :2]) per view).  render_batch with one
+    gradient carrier PER VIEW gives each carrier exactly the gradient a separate render() of that view gives; with one shared
+    carrier the gradient is the sum over the views (autograd's semantics), which those statistics must not be fed."""
+    from gaus_slam_amd import render as gs_render
+    dev = torch.device("cuda", 0)
+    W, H, P, K = 320, 240, 20000, 3
+    sc = util.make_scene(P, W, H, seed=19, regime="mapping")
+    cams = _cameras(sc, K, 13)
+    sts = [gs_render.settings_from_camera(c, dev, use_sa=True) for c in cams]
+    p = {k: sc[k].to(dev).requires_grad_(True) for k in ("means3D", "opacities", "scales", "rotations", "colors")}
+    ups = []
+    for k in range(K):
+        dc, da = util.make_upstream_grads(W, H, seed=30 + k, channels=(0, 1, 5, 6))
+        ups.append(((dc * W * H).to(dev), (da * W * H).to(dev)))
+    sep = []
+    for k in range(K):
+        m2 = torch.zeros_like(p["means3D"]).requires_grad_(True)
+        pk = gs_render.render(sts[k], p["means3D"], m2, p["opacities"], colors_precomp=p["colors"], scales=p["scales"],
+                              rotations=p["rotations"])
+        torch.autograd.backward([pk["render_color"], pk["allmap"]], list(ups[k]))
+        assert pk["means2D"] is m2 and float(m2.grad.abs().max()) > 0
+        sep.append(m2.grad.clone())
+    g_param_sep = {k: v.grad.clone() for k, v in p.items()}
+    for v in p.values():
+        v.grad = None
+    # one carrier per view
+    m2s = [torch.zeros_like(p["means3D"]).requires_grad_(True) for _ in range(K)]
+    pks = gs_render.render_batch(sts, p["means3D"], m2s, p["opacities"], colors_precomp=p["colors"], scales=p["scales"],
+                                 rotations=p["rotations"])
+    outs, gs = [], []
+    for k, pk in enumerate(pks):
+        assert pk["means2D"] is m2s[k]
+        outs += [pk["render_color"], pk["allmap"]]
+        gs += list(ups[k])
+    torch.autograd.backward(outs, gs)
+    for k in range(K):
+        assert util.grad_err(m2s[k].grad.cpu().numpy(), sep[k].cpu().numpy()) <= 1e-5, k
+        # what the reference's statistic sees for view k
+        assert torch.allclose(m2s[k].grad[:, :2].norm(dim=-1), sep[k][:, :2].norm(dim=-1), rtol=1e-4, atol=1e-7 * float(sep[k].abs().max()))
+    for k2, v in p.items():  # the parameter gradients are the sums over the views, as K separate calls accumulate them
+        assert util.grad_err(v.grad.cpu().numpy(), g_param_sep[k2].cpu().numpy()) <= 1e-5, k2
+        v.grad = None
+    # one shared carrier: the sum over the views
+    m2 = torch.zeros_like(p["means3D"]).requires_grad_(True)
+    pks = gs_render.render_batch(sts, p["means3D"], m2, p["opacities"], colors_precomp=p["colors"], scales=p["scales"],
+                                 rotations=p["rotations"])
+    outs = []
+    for pk in pks:
+        outs += [pk["render_color"], pk["allmap"]]
+    torch.autograd.backward(outs, gs)
+    assert util.grad_err(m2.grad.cpu().numpy(), sum(sep).cpu().numpy()) <= 1e-5
+
+
+def test_batch_camera_cache_sees_an_in_place_pose_update():
+    """the stacked camera matrices of a frame set are cached by the identity of the settings objects; a pose refined
+    IN PLACE (the tensors of a NamedTuple can be written) must not render with the stale stack."""
+    from gaus_slam_amd import render as gs_render
+    from gaus_slam_amd.scene_synth import random_w2c, setup_camera
+    dev = torch.device("cuda", 0)
+    W, H, P = 160, 120, 3000
+    sc = util.make_scene(P, W, H, seed=23, regime="mapping")
+    cams = _cameras(sc, 2, 5)
+    sts = [gs_render.settings_from_camera(c, dev, use_sa=True) for c in cams]
+    p = {k: sc[k].to(dev) for k in ("means3D", "opacities", "scales", "rotations", "colors")}
+    m2 = torch.zeros_like(p["means3D"])
+    kw = dict(colors_precomp=p["colors"], scales=p["scales"], rotations=p["rotations"])
+    before = gs_render.render_batch(sts, p["means3D"], m2, p["opacities"], **kw)[1]["render_color"].clone()
+    new = setup_camera(W, H, sc["cam"].K, random_w2c(np.random.default_rng(77), 6.0, 0.2) @ sc["cam"].w2c)
+    sts[1].viewmatrix.copy_(new.viewmatrix.to(dev).unsqueeze(0))
+    sts[1].projmatrix.copy_(new.projmatrix.to(dev).unsqueeze(0))
+    sts[1].campos.copy_(new.campos.to(dev))
+    after = gs_render.render_batch(sts, p["means3D"], m2, p["opacities"], **kw)[1]["render_color"]
+    single = gs_render.render(sts[1], p["means3D"], m2, p["opacities"], **kw)["render_color"]
+    assert torch.equal(after, single) and not torch.equal(after, before)
+
+
+def test_ba_step_with_a_batch_fn_in_deterministic_mode():
+    """the batched backward has no deterministic variant; with gs2d_set_deterministic(1) a rank that holds several
+    keyframes must take them one by one (bit-identical from run to run) instead of failing in the middle of the step."""
+    from gaus_slam_amd import ba_shard, rasterizer, render as gs_render
+    dev = torch.device("cuda", 0)
+    W, H, P, K = 256, 192, 12000, 3
+    sc = util.make_scene(P, W, H, seed=29, regime="mapping")
+    cams = _cameras(sc, K, 17)
+    sts = [gs_render.settings_from_camera(c, dev, use_sa=True) for c in cams]
+    names = ("means3D", "opacities", "scales", "rotations", "colors")
+    ups = []
+    for k in range(K):
+        dc, da = util.make_upstream_grads(W, H, seed=40 + k, channels=(0, 1, 5, 6))
+        ups.append(((dc * W * H).to(dev), (da * W * H).to(dev)))
+
+    def one(p, kf):
+        m2 = torch.empty_like(p["means3D"]).requires_grad_(True)
+        pk = gs_render.render(sts[kf], p["means3D"], m2, p["opacities"], colors_precomp=p["colors"], scales=p["scales"],
+                              rotations=p["rotations"])
+        return (pk["render_color"], pk["allmap"]), ups[kf]
+
+    def batch(p, kfs):
+        m2 = torch.empty_like(p["means3D"]).requires_grad_(True)
+        pks = gs_render.render_batch([sts[k] for k in kfs], p["means3D"], m2, p["opacities"], colors_precomp=p["colors"],
+                                     scales=p["scales"], rotations=p["rotations"])
+        outs, gs = [], []
+        for k, pk in zip(kfs, pks):
+            outs += [pk["render_color"], pk["allmap"]]
+            gs += list(ups[k])
+        return outs, gs
+
+    def run():
+        params = {k: sc[k].to(dev).requires_grad_(True) for k in names}
+        ba = ba_shard.KeyframeShardedBA(params, one, direct_grads=True, batch_fn=batch)
+        g = ba.step(list(range(K)))
+        torch.cuda.synchronize()
+        return {n: g[n].cpu().numpy().copy() for n in names}
+
+    ref = run()  # (batched, atomics)
+    rasterizer.set_deterministic(True)
+    try:
+        a, b = run(), run()
+    finally:
+        rasterizer.set_deterministic(False)
+    for n in names:
+        assert np.array_equal(a[n].view(np.uint32), b[n].view(np.uint32)), n
+        assert util.grad_err(a[n], ref[n]) <= 1e-5, n
