@@ -20,6 +20,19 @@
 // Arithmetic follows the oracle's expression order; the file is compiled with -ffp-contract=off so the
 // per-pixel recurrences reproduce the CPU oracle up to the ulp-level difference of v_exp_f32 / v_rcp_f32.
 #include "gs2d_common.h"
+#ifndef GS2D_BWD_GROUPS
+#define GS2D_BWD_GROUPS 4       // queues per wave of the full backward: 4 (one per 4x4 sub-block = DPP row) or 8 (one per 4x2 half-row)
+#endif
+#ifndef GS2D_BWD_POSE_GROUPS
+#define GS2D_BWD_POSE_GROUPS 4  // ... of the pose-only backward
+#endif
+// eight queues anywhere: the forward's phase 0 stores eight half-row cull bits per (instance, quadrant) instead of four row bits
+#define GS2D_HALFROW_BITS (GS2D_BWD_GROUPS == 8 || GS2D_BWD_POSE_GROUPS == 8)
+#ifndef GS2D_BWD_LANE_CLASH
+#define GS2D_BWD_LANE_CLASH 1   // four queues, full backward: the LDS-atomic fallback of the accumulate is decided per LANE (a flag in
+                                // bit 6 of the queue entry) instead of per trip: 0.2385 -> 0.2331 ms (profiles/bwd_queue_ab_r04.txt);
+                                // the pose-only kernel keeps the per-trip test (per lane measured 3 % slower there)
+#endif
 #include "gs2d_cull.h"
 #include "gs2d_tile_sort.h"
 #include "gs2d_blend_dev.h"  // dev-only probes (wave profile, ingredient pricing): all pass-through in the product build
@@ -601,6 +614,85 @@ __device__ __forceinline__ float reduce3_row(float v0, float v1, float v2)
     return g + dpp_get<0xB1>(g);             // quad_perm [1,0,3,2]
 }
 
+// --- the same for EIGHT queues per wave (one per 8-lane half of a DPP row = 4x2 pixels): 16 values summed over the 8 lanes of a
+// half, two results per lane.  Levels: half-mirror (l <-> 7-l, bank-masked, no selects), then the two quad levels as
+// select-adds.  Lane l of a half (b2 b1 b0 = its low three bits) ends with value 4 b0 + 2 b1 + b2 in `lo` and 8 + that in `hi`.
+__device__ __forceinline__ void reduce16_half(const float v[16], int lane, float& lo, float& hi)
+{
+    float e0, e1, e2, e3, e4, e5, e6, e7;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %10, %10 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %12, %12 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %14, %14 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %16, %16 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %18, %18 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %20, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %7, %22, %22 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %11, %11 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %13, %13 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %15, %15 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %4, %17, %17 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %5, %19, %19 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %6, %21, %21 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %7, %23, %23 row_half_mirror row_mask:0xf bank_mask:0xa"
+        : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(e4), "=&v"(e5), "=&v"(e6), "=&v"(e7)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]),
+          "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+    const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+    const float f0 = seladd<0x4E>(e0, e1, b1), f1 = seladd<0x4E>(e2, e3, b1);
+    const float f2 = seladd<0x4E>(e4, e5, b1), f3 = seladd<0x4E>(e6, e7, b1);
+    lo = seladd<0xB1>(f0, f1, b0);
+    hi = seladd<0xB1>(f2, f3, b0);
+}
+__device__ __forceinline__ int reduce16_half_index(int lane)  // the value `lo` holds (hi: + 8)
+{
+    return 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
+}
+// three values over the 8 lanes of a half (pose-only backward with eight queues): lanes 0-3 of the half end with the total of
+// v0 in `a`, lanes 4-7 with that of v1; every lane has the total of v2 in `b`
+__device__ __forceinline__ void reduce3_half(float v0, float v1, float v2, float& a, float& b)
+{
+    float e0, e1;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa"
+        : "=&v"(e0), "=&v"(e1) : "v"(v0), "v"(v1), "v"(v2));
+    const float g0 = e0 + dpp_get<0x4E>(e0), g1 = e1 + dpp_get<0x4E>(e1);
+    a = g0 + dpp_get<0xB1>(g0);
+    b = g1 + dpp_get<0xB1>(g1);
+}
+// the value of the lane 8 further on in the same 16-lane row (row_ror:8): what the OTHER half of the row holds
+__device__ __forceinline__ float dpp_other_half(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint32_t dpp_other_half(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);
+}
+// Eight queues: the two halves of a row often hold the SAME splat in a trip (a splat that covers both halves of a 4x4 sub-block
+// sits at about the same place of both queues).  Left alone, their totals meet on one accumulator -- the LDS-atomic path, which
+// cost the eight-queue kernel all it had gained (0.166 vs 0.147 ms with the atomics compiled out, pose-only backward).  So the
+// twins are merged in registers: the lower half adds the upper half's total to its own, the upper half drops its own.
+// twin_m: lanes whose row's halves hold the same slot; lo_m / hi_m: the lanes of the lower / upper halves (wave masks).
+__device__ __forceinline__ float merge_twin_halves(float tot, uint64_t twin_lo_m, uint64_t twin_hi_m)
+{
+    const float other = dpp_other_half(tot);
+    tot = __builtin_amdgcn_inverse_ballot_w64(twin_lo_m) ? tot + other : tot;
+    return __builtin_amdgcn_inverse_ballot_w64(twin_hi_m) ? 0.f : tot;
+}
+// sum over the 8 lanes of each half of a row, valid in lanes 7 and 15 of the row (rare low-pass branch, eight queues)
+__device__ __forceinline__ float half_sum_to_lane7(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    return v;
+}
+
 // Gradient record (GS2D_GRAD_FLOATS = 20 floats per Gaussian):
 //   [0..2] dL_dcolor  [3..5] dL_dnormal  [6..14] dL_dT (Tu,Tv,Tw)  [15] dL_dopacity  [16,17] dL_dmean2D.xy
 //
@@ -632,18 +724,29 @@ __device__ __forceinline__ float reduce3_row(float v0, float v1, float v2)
 // the accumulator at the end of the trip (0.338 ms, the latency enters the dependency chain), merging twin rows' totals
 // with v_permlane16/32_swap so that no trip needs the atomic (0.330 ms, +4 spills), and a per-row instead of
 // wave-uniform fallback (no change).
-#define GS2D_BWD_ACC_PRE(JJ)                                                                                            \
+#define GS2D_BWD_ACC_PRE(JJ, FJ_)                                                                                        \
     const int ai_ = (int)__umul24((JJ), (uint32_t)NACC) + (acc_comp < 0 ? 0 : acc_comp); /* v_mul_lo_u32 is quarter rate */ \
     const float acc_old_ = wb.acc()[ai_];                                                                                 \
+    /* eight queues, full kernel: the lane's second value (reduce16_half) has an accumulator of its own */               \
+    const int ai2_ = ai_ - (acc_comp < 0 ? 0 : acc_comp) + (acc_comp_hi < 0 ? 0 : acc_comp_hi);                         \
+    float acc_old2_ = 0.f;                                                                                              \
+    if (NG == 8 && !POSE) acc_old2_ = wb.acc()[ai2_];                                                                    \
     /* do two rows hold the same splat in this trip?  Decided for all trips of the batch at once when the queues are    \
        built (clash_mask, one bit per trip): one scalar bit test here instead of four v_readlane + a scalar compare     \
        chain per trip */                                                                                                \
-    const bool clash_ = ((clash_mask >> t) & 1ull) != 0ull;
+    /* eight queues: per LANE instead (the flag rides in bit 6 of the queue entry, see the queue build): with eight queues   \
+       some two of them meet in a good share of the trips, and an LDS float atomic costs by the lane */               \
+    const bool clash_ = GS2D_DEV_CLASH(LANE_CLASH ? __builtin_amdgcn_inverse_ballot_w64(FJ_) : ((clash_mask >> t) & 1ull) != 0ull);
 #ifndef GS2D_BWD_LDS_ACCUM  // (gs2d_blend_dev.h may have replaced it in an experiment build)
 #define GS2D_BWD_LDS_ACCUM(JJ, V)                                                                                       \
     if ((V) != 0.f) {                                                                                                   \
         if (clash_) atomicAdd(&wb.acc()[ai_], V);                                                                         \
         else wb.acc()[ai_] = acc_old_ + (V);                                                                              \
+    }
+#define GS2D_BWD_LDS_ACCUM2(JJ, V)                                                                                      \
+    if ((V) != 0.f) {                                                                                                   \
+        if (clash_) atomicAdd(&wb.acc()[ai2_], V);                                                                        \
+        else wb.acc()[ai2_] = acc_old2_ + (V);                                                                            \
     }
 #endif
 // dev A/B switches (scripts/dev/variants.sh) for the wave-level "does any lane contribute?" shortcuts of the trip step.
@@ -666,7 +769,7 @@ __device__ __forceinline__ float reduce3_row(float v0, float v1, float v2)
 #define GS2D_ACC 13
 #define GS2D_ACC_DET 18
 #define GS2D_ACC_POSE 3   // pose-only backward: dT[2], dT[5], dT[8] -- all dL/dmean needs (gs2d_preprocess.hip, backward.cu:637-663)
-template <int NACC>
+template <int NACC, int NQ = 4>
 struct BwdBatchT {
     // Entries past a queue's end hold slot 63 -- the deepest staged splat, always a real record -- and a row is live while the
     // trip number is below its queue length: an exhausted row evaluates a real (finite) record with all its lanes inactive,
@@ -676,12 +779,18 @@ struct BwdBatchT {
     // `!= 0` test of the accumulate and lands behind the accumulator array -- a corrupted Gaussian id and a memory fault in
     // the flush, caught by tests/test_gpu_batch.py.)
     float raw[4 * 64 * 4 + 64 * NACC];  // q: 4 quarters x 64 slots x float4 (Tu|cx, Tv|cy, Tw|opacity, r g b position), then acc
-    uint32_t pn[64];    // Gaussian id | cull bits << 28 of the staged splat (read when queues are built and at the flush only)
     __device__ __forceinline__ float4* q(int k) { return reinterpret_cast<float4*>(raw) + k * 64; }
     __device__ __forceinline__ float* acc() { return raw + 4 * 64 * 4; }
-    uint8_t ql[4][64];  // per-row queues: slot numbers, deepest first, then 63s
-    uint32_t tail[4];   // the pipeline reads up to two entries past a full queue (values unused)
+    uint32_t pn[64];    // Gaussian id | four cull bits << 28 of the staged splat (read when queues are built and at the flush only;
+                        // with eight queues the other four bits ride in the top of the position word until the queues are built)
+    uint8_t ql[NQ][64]; // per-group queues: slot numbers, deepest first, then 63s
+    uint32_t tail[NQ == 4 ? 4 : 1];  // four queues: the pipeline reads up to two entries past a full queue (slot 63 again); eight
+                                     // queues have no LDS left for that (32 768 B is the last size with five workgroups per CU,
+                                     // scripts/dev/lds_occupancy_probe) and clamp the read-ahead index instead
+    static constexpr int BYTES = 4 * (4 * 64 * 4 + 64 * NACC) + 256 + 64 * NQ + (NQ == 4 ? 16 : 0);  // what the kernel allocates
 };
+static_assert(BwdBatchT<GS2D_ACC, 4>::BYTES == 7952 && BwdBatchT<GS2D_ACC, 8>::BYTES == 8192, "blend_bwd LDS budget: 31 808 / 32 768 B per workgroup");
+static_assert(sizeof(BwdBatchT<GS2D_ACC, 4>) == 7952, "BwdBatchT<13, 4>: 4 x 7952 = 31 808 B, five workgroups per CU");
 
 // POSE (tracking with every Gaussian parameter detached, render/__init__.py:31-36; chosen by gs2d_backward_staged when all six
 // per-Gaussian outputs are NULL): the pose gradient needs dL/dmean = Pm^T (dT[2], dT[5], dT[8]) only (backward.cu:637-663; plus
@@ -690,7 +799,10 @@ struct BwdBatchT {
 // throws away), reduces them with the 3-value row reduction, keeps 3 accumulators per staged splat and flushes them into a
 // DENSE float4-per-Gaussian array laid over the head of the (forward-cleared) gradient records; dL_dmean2D goes to
 // dense_m2d[2 g].  Single frame, non-deterministic mode only.
-template <bool USE_SA, bool DET, bool BATCH, bool POSE = false>
+// NG: queues per wave.  4: one per 16-lane DPP row (4x4 pixels), the 16 gradient components of a (row, splat) pair end as one
+// value per lane.  8: one per 8-lane half-row (4x2 pixels): fewer loop trips (a trip ends when the LONGEST queue has moved on;
+// scripts/dev/group_trips.c: -13.5 % at the bench size), but two values per lane to accumulate (reduce16_half).
+template <bool USE_SA, bool DET, bool BATCH, bool POSE = false, int NG = (DET ? 4 : (POSE ? GS2D_BWD_POSE_GROUPS : GS2D_BWD_GROUPS))>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DET ? 4 : GS2D_WAVES_PER_EU, DET ? 4 : GS2D_WAVES_PER_EU)))
 blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const float* __restrict__ bg, size_t plane,
                  float* __restrict__ clear12, int clear_n,
@@ -698,9 +810,14 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
 {
     if (clear12 != nullptr && blockIdx.x == 0 && (int)threadIdx.x < clear_n) clear12[threadIdx.x] = 0.f;
     static_assert(!(POSE && (DET || BATCH)), "the pose-only backward is single-frame and non-deterministic");
+    static_assert(NG == 4 || (NG == 8 && !DET), "queues per wave: 4, or 8 in the non-deterministic kernels");
+    // the LDS-atomic fallback of the accumulate decided per LANE (flag in bit 6 of the queue entry) instead of per trip
+    constexpr bool LANE_CLASH = NG == 8 || (GS2D_BWD_LANE_CLASH && !DET && !POSE);
     constexpr int NACC = DET ? GS2D_ACC_DET : (POSE ? GS2D_ACC_POSE : GS2D_ACC);
-    typedef BwdBatchT<NACC> BwdBatch;
-    __shared__ BwdBatch batches[4];
+    typedef BwdBatchT<NACC, NG> BwdBatch;
+    // (a byte array of exactly 4 x BYTES: the eight-queue struct is declared with a one-word `tail` it never touches, the
+    // allocation ends with its last queue)
+    __shared__ __attribute__((aligned(16))) unsigned char batch_mem[4 * BwdBatch::BYTES + GS2D_DEV_LDS_PAD];
     int local_block = blockIdx.x;
     const gs2d::BlendBwdFrame* fa;
     if constexpr (BATCH) {  // see blend_fwd_kernel
@@ -724,11 +841,12 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    BwdBatch& wb = batches[wave];
+    BwdBatch& wb = *reinterpret_cast<BwdBatch*>(batch_mem + wave * BwdBatch::BYTES);
     const int qx0 = tx * GS2D_TILE + (wave & 1) * 8, qy0 = ty * GS2D_TILE + (wave >> 1) * 8;
     const int row = lane >> 4, li = lane & 15;                       // DPP row = 4x4 sub-block (same mapping as the forward)
-    const int row8 = row * 8;
-    const uint8_t* qrow = wb.ql[row];
+    const int grp = NG == 8 ? lane >> 3 : row;                       // the queue this lane follows (NG == 8: lanes 0-7 of a row =
+    const int grp8 = grp * 8;                                        // its pixel rows 0-1, lanes 8-15 = pixel rows 2-3)
+    const uint8_t* qrow = wb.ql[grp];
     const int px = qx0 + (row & 1) * 4 + (li & 3), py = qy0 + (row >> 1) * 4 + (li >> 2);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
@@ -793,9 +911,10 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     // splats out (the quadrant-level bound above only decides where the walk starts; 954k -> 933k trips per frame)
     uint32_t row_last = last_contributor;
 #pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) row_last = max(row_last, (uint32_t)__shfl_xor((int)row_last, d, 64));
-    const uint32_t row_last0 = (uint32_t)__builtin_amdgcn_readlane((int)row_last, 0), row_last1 = (uint32_t)__builtin_amdgcn_readlane((int)row_last, 16),
-                   row_last2 = (uint32_t)__builtin_amdgcn_readlane((int)row_last, 32), row_last3 = (uint32_t)__builtin_amdgcn_readlane((int)row_last, 48);
+    for (int d = (NG == 8 ? 4 : 8); d >= 1; d >>= 1) row_last = max(row_last, (uint32_t)__shfl_xor((int)row_last, d, 64));
+    uint32_t grp_last[NG];  // (wave-uniform: scalar registers)
+#pragma unroll
+    for (int g = 0; g < NG; g++) grp_last[g] = (uint32_t)__builtin_amdgcn_readlane((int)row_last, g * (64 / NG));
     max_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_last);
 
     // butterfly slot held by this lane -> offset in the gradient record, and the sign of that component.  Slots:
@@ -803,11 +922,18 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     const int slot = reduce16_row_index(lane);
     // LDS accumulator of this lane's slot; -1: normal component, added straight to the global record (not in DET: 13..15)
     // (POSE: reduce3_row leaves the totals of -dk.z / -dl.z / Tw.z in quads 0 / 2 / 1 of the row; one lane of each adds them up)
-    const int acc_comp = POSE ? (li == 0 ? 0 : (li == 8 ? 1 : (li == 4 ? 2 : -1)))
+    // NG == 8: reduce16_half leaves values h and 8 + h in every lane (h = reduce16_half_index): the first is always an LDS
+    // accumulator (0-7), the second one of 8-11, a normal component (12-14) or the opacity (15 -> accumulator 12);
+    // POSE: reduce3_half leaves -dk.z in lanes 0-3 of a half, -dl.z in lanes 4-7, Tw.z everywhere: lanes 0, 4 and 2 add them up
+    const int half_idx = reduce16_half_index(lane);
+    const int acc_comp = NG == 8 ? (POSE ? ((li & 7) == 0 ? 0 : ((li & 7) == 4 ? 1 : ((li & 7) == 2 ? 2 : -1))) : half_idx)
+                       : POSE ? (li == 0 ? 0 : (li == 8 ? 1 : (li == 4 ? 2 : -1)))
                               : (slot < 12 ? slot : (slot == 15 ? 12 : (DET ? slot + 1 : -1)));
+    const int acc_comp_hi = half_idx < 4 ? 8 + half_idx : (half_idx == 7 ? 12 : -1);  // NG == 8, full kernel: the second value
+    const uint64_t lo_half_m = ballot64((li & 8) == 0);                               // lanes of the lower halves of the rows
 #pragma unroll
     for (int i = 0; i < NACC; i++) wb.acc()[i * 64 + lane] = 0.f;
-    if (lane < 4) wb.tail[lane] = 0x3F3F3F3Fu;
+    if (NG == 4 && lane < 4) wb.tail[lane] = 0x3F3F3F3Fu;
     // Wave-uniform data-dependent shortcut: when no pixel of this quadrant carries an upstream gradient on the
     // normal channels (SLAM's losses never touch them unless use_normal_loss), everything that only feeds
     // dL_dnormal / the normal term of dL_dalpha is exactly zero and is skipped.  Results are unchanged.
@@ -854,8 +980,9 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                 if (chunk < 0) break;
                 cb = chunk--;
                 const int n = (int)min(64u, max_last - (uint32_t)cb * 64u);
-                // queues come from the cull bits of this (instance, quadrant)
-                tm = lane < n ? pf_tm : 0u;
+                // queues come from the cull bits of this (instance, quadrant): eight half-row bits, ORed to four row bits here
+                // when the wave keeps four queues
+                tm = lane < n ? ((NG == 8 || !GS2D_HALFROW_BITS) ? pf_tm : rows_from_halfrows(pf_tm)) : 0u;
                 my_id = pf_id;
                 const uint32_t nb = min(range.x + (uint32_t)max(chunk, 0) * 64u + lane, last_i);
                 pf_tm = hits[(size_t)nb * 4 + wave];
@@ -868,8 +995,10 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
             const int slot = 64 - fill - c + rank_below(tb);
             const bool take = tm != 0u && slot >= 0;
             if (take) {
-                wb.q(3)[slot].w = __uint_as_float((uint32_t)cb * 64u + lane);  // the list position
-                wb.pn[slot] = my_id | (tm << 28);                             // Gaussian id (< 2^28, checked by the API) + cull bits
+                // the list position (< 2^28: a Gaussian is in a tile's list at most once); with eight queues the upper four
+                // cull bits ride on top of it until the queues are built
+                wb.q(3)[slot].w = __uint_as_float(((uint32_t)cb * 64u + lane) | (NG == 8 ? (tm >> 4) << 28 : 0u));
+                wb.pn[slot] = my_id | ((tm & 15u) << 28);                     // Gaussian id (< 2^28, checked by the API) + cull bits
             }
             if (fill + c > 64) { carry_tm = take ? 0u : tm; carry_id = my_id; carry_chunk = cb; fill = 64; break; }
             fill += c;
@@ -891,50 +1020,117 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
         // four depth-ordered queues, one per 4x4 sub-block (= DPP row): byte lists of slot numbers, deepest (= highest
         // slot) first, so walking a list front to back visits the row's splats back to front
         uint32_t nib = lane >= 64 - fill ? wb.pn[lane] >> 28 : 0u;
+        {
+            const uint32_t posw = __float_as_uint(wb.q(3)[lane].w);
+            const uint32_t pos = posw & 0x0FFFFFFFu;
+            if (NG == 8) {  // the upper four bits come off the position word, which the trip loop reads as a plain number
+                if (lane >= 64 - fill) { nib |= (posw >> 28) << 4; wb.q(3)[lane].w = __uint_as_float(pos); }
+            }
 #ifndef GS2D_NO_ROW_LAST  // dev A/B switch (scripts/dev/variants.sh)
-        {   // row r keeps the splat only if it lies in front of the row's deepest contributor (pos < row_last_r)
-            const uint32_t pos = __float_as_uint(wb.q(3)[lane].w);
-            nib &= (pos < row_last0 ? 1u : 0u) | (pos < row_last1 ? 2u : 0u) | (pos < row_last2 ? 4u : 0u) | (pos < row_last3 ? 8u : 0u);
-        }
+            // group g keeps the splat only if it lies in front of the group's deepest contributor (pos < grp_last[g])
+            uint32_t keep = 0u;
+#pragma unroll
+            for (int g = 0; g < NG; g++) keep |= pos < grp_last[g] ? (1u << g) : 0u;
+            nib &= keep;
 #endif
-        const uint64_t m0 = ballot64(nib & 1u), m1 = ballot64(nib & 2u), m2 = ballot64(nib & 4u), m3 = ballot64(nib & 8u);
-        const int len0 = __popcll(m0), len1 = __popcll(m1), len2 = __popcll(m2), len3 = __popcll(m3);
+        }
+        uint64_t gm[NG];
+        int glen[NG];
+        int trips = 0;  // (0: nothing staged lies in front of its groups' deepest contributors -- one idle step)
+        uint64_t lens_packed = 0ull;
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            gm[g] = ballot64((nib >> g) & 1u);
+            glen[g] = __popcll(gm[g]);
+            trips = max(trips, glen[g]);
+            lens_packed |= (uint64_t)(uint32_t)glen[g] << (8 * g);
+        }
         // every entry past a queue's end reads slot 63 (see BwdBatchT)
-        reinterpret_cast<uint32_t*>(wb.ql)[lane] = 0x3F3F3F3Fu;
-        const int mylen = row_select(row8, len0, len1, len2, len3);  // this lane's row is live in trips 0 .. mylen - 1
-        if (nib & 1u) wb.ql[0][len0 - 1 - rank_below(m0)] = (uint8_t)lane;
-        if (nib & 2u) wb.ql[1][len1 - 1 - rank_below(m1)] = (uint8_t)lane;
-        if (nib & 4u) wb.ql[2][len2 - 1 - rank_below(m2)] = (uint8_t)lane;
-        if (nib & 8u) wb.ql[3][len3 - 1 - rank_below(m3)] = (uint8_t)lane;
-        const int trips = max(max(len0, len1), max(len2, len3));  // (0: nothing staged lies in front of its rows' deepest contributors -- one idle step)
+#pragma unroll
+        for (int w = 0; w < NG / 4; w++) reinterpret_cast<uint32_t*>(wb.ql)[lane + 64 * w] = 0x3F3F3F3Fu;
+        const int mylen = (int)((lens_packed >> grp8) & 0xffull);  // this lane's group is live in trips 0 .. mylen - 1
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+            if ((nib >> g) & 1u) wb.ql[g][glen[g] - 1 - rank_below(gm[g])] = (uint8_t)lane;
         wave_lds_sync();
-        // bit t: in trip t two LIVE rows hold the same splat: their totals then meet on one accumulator -- LDS atomic instead of
-        // the plain store, GS2D_BWD_LDS_ACCUM
+        // bit t: in trip t two LIVE groups hold the same splat: their totals then meet on one accumulator -- LDS atomic instead
+        // of the plain store, GS2D_BWD_LDS_ACCUM
         uint64_t clash_mask;
         {
-            const uint32_t qa = wb.ql[0][lane], qb = wb.ql[1][lane], qc = wb.ql[2][lane], qd = wb.ql[3][lane];
-            const bool la = lane < len0, lb = lane < len1, lc = lane < len2, ld = lane < len3;
-            clash_mask = ballot64((la && ((lb && qa == qb) || (lc && qa == qc) || (ld && qa == qd))) ||
-                                  (lb && ((lc && qb == qc) || (ld && qb == qd))) || (lc && ld && qc == qd));
+            uint64_t seen = 0ull;
+            bool clash = false;
+            uint32_t prev_e = 0u;
+            bool prev_live = false;
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const bool live = (int)lane < glen[g];
+                const uint32_t e = wb.ql[g][lane];
+                // (eight queues: the upper half of a row holding its lower half's splat is merged in registers, merge_twin_halves)
+                const bool twin = NG == 8 && (g & 1) && live && prev_live && e == prev_e;
+                const uint64_t bit = live && !twin ? 1ull << e : 0ull;
+                clash = clash || (seen & bit) != 0ull;
+                seen |= bit;
+                prev_e = e; prev_live = live;
+            }
+            clash_mask = ballot64(clash);
+            if (LANE_CLASH) {
+                // which GROUPS meet on a splat in this trip: their queue entries get bit 6 set (slot numbers are 0-63); the
+                // trip loop takes the flag off when it loads an entry and sends only those lanes through the LDS atomic
+                // The WRITERS of a trip, exactly as the trip loop will have them: the two halves of a row whose entries are equal
+                // (exhausted halves read the sentinel, slot 63) are merged in registers and written by the LOWER half's lanes
+                // -- even when only the upper half is live; otherwise every live half writes for itself.
+                uint64_t once = 0ull, twice = 0ull;
+                uint32_t es[NG];
+                bool ws[NG];
+#pragma unroll
+                for (int r = 0; r < NG / 2; r++) {
+                    const bool l_lo = (int)lane < glen[2 * r], l_hi = (int)lane < glen[2 * r + 1];
+                    const uint32_t e_lo = wb.ql[2 * r][lane], e_hi = wb.ql[2 * r + 1][lane];
+                    const bool merged = NG == 8 && e_lo == e_hi;  // (four queues: no merging, every live row writes for itself)
+                    es[2 * r] = e_lo; es[2 * r + 1] = e_hi;
+                    ws[2 * r] = merged ? (l_lo || l_hi) : l_lo;
+                    ws[2 * r + 1] = merged ? false : l_hi;
+                }
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    const uint64_t bit = ws[g] ? 1ull << es[g] : 0ull;
+                    twice |= once & bit;
+                    once |= bit;
+                }
+                if (twice != 0ull) {
+#pragma unroll
+                    for (int g = 0; g < NG; g++)
+                        if (ws[g] && ((twice >> es[g]) & 1ull)) wb.ql[g][lane] = (uint8_t)(es[g] | 0x40u);
+                }
+                wave_lds_sync();
+            }
         }
         GS2D_PROF_STAGE_END();
         // software pipeline: queue entries are read two trips ahead, records one trip ahead
         int t = 0;
         uint32_t j = qrow[0], jx = qrow[1];
+        uint64_t fj = 0ull, fjx = 0ull;  // eight queues: "this lane's group meets another one on its splat" for the entries in j, jx
+        if (LANE_CLASH) { fj = ballot64(j > 63u); fjx = ballot64(jx > 63u); j &= 63u; jx &= 63u; }
         float4 ga0 = wb.q(0)[j], ga1 = wb.q(1)[j], ga2 = wb.q(2)[j];
         float4 gb0, gb1, gb2;
-#define GS2D_BWD_STEP(G0, G1, G2, J, N0_, N1_, N2_, JN)                                                                  \
+#define GS2D_BWD_STEP(G0, G1, G2, J, N0_, N1_, N2_, JN, FJ_)                                                             \
         {                                                                                                             \
             GS2D_PROF_TRIP();                                                                                         \
-            uint32_t jnn = qrow[t + 2];                                                                               \
+            uint32_t jnn = qrow[NG == 8 ? min(t + 2, 63) : t + 2]; /* (eight queues: nothing to over-read into, see BwdBatchT) */ \
             asm volatile("" : "+v"(jnn)); /* a full 32-bit value from here on: ds_read_u8 zero-extends, no v_and 0xff later */ \
+            uint64_t fnn_ = 0ull;                                                                                     \
+            if (LANE_CLASH) { fnn_ = ballot64(jnn > 63u); jnn &= 63u; }                                               \
             N0_ = wb.q(0)[JN]; N1_ = wb.q(1)[JN]; N2_ = wb.q(2)[JN];                                                  \
             const float4 cc = wb.q(3)[J]; /* r, g, b, list position */                                                \
             const uint32_t contributor = __float_as_uint(cc.w); /* 0-based, as in backward.cu:285 */                  \
             /* "this lane contributes" as a wave mask in scalar registers (tests on it are scalar compares, not v_cndmask + v_cmp) */ \
             uint64_t am = ballot64(t < mylen) & ballot64(contributor < last_contributor); /* past its queue's end the row idles; outside: last = 0 */ \
             if (GS2D_BWD_SKIP1(am != 0ull)) {                                                                          \
-                GS2D_BWD_ACC_PRE(J)                                                                                   \
+                GS2D_BWD_ACC_PRE(J, FJ_)                                                                              \
+                /* eight queues: do the two halves of my row hold the same splat in this trip? (an exhausted half holds slot \
+                   63 with an all-zero total: merging it is harmless) */                                              \
+                uint64_t twin_m_ = 0ull;                                                                              \
+                if (NG == 8) twin_m_ = ballot64(dpp_other_half((uint32_t)(J)) == (uint32_t)(J));                      \
                 /* Part A (all lanes): same geometry / alpha as the forward */                                        \
                 const float k0 = fmaf(pxf, G2.x, -G0.x), k1 = fmaf(pxf, G2.y, -G0.y), k2 = fmaf(pxf, G2.z, -G0.z);    \
                 const float l0 = fmaf(pyf, G2.x, -G1.x), l1 = fmaf(pyf, G2.y, -G1.y), l2 = fmaf(pyf, G2.z, -G1.z);    \
@@ -1008,7 +1204,12 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                     if (POSE) { /* the z components only: the same expressions as g[5], g[8], g[11] below */          \
                         const float nk2 = fmaf(l1, dsx, -(l0 * dsy));                                                 \
                         const float nl2 = fmaf(dsy, k0, -(dsx * k1));                                                 \
-                        tot = reduce3_row(nk2, nl2, fmaf(-pxf, nk2, fmaf(-pyf, nl2, d_zr)) + d_zl);                   \
+                        if (NG == 8) {                                                                                \
+                            float ta_, tb_;                                                                           \
+                            reduce3_half(nk2, nl2, fmaf(-pxf, nk2, fmaf(-pyf, nl2, d_zr)) + d_zl, ta_, tb_);          \
+                            tot = merge_twin_halves((li & 7) == 2 ? tb_ : ta_, twin_m_ & lo_half_m, twin_m_ & ~lo_half_m); \
+                        } else                                                                                        \
+                            tot = reduce3_row(nk2, nl2, fmaf(-pxf, nk2, fmaf(-pyf, nl2, d_zr)) + d_zl);               \
                         if (acc_comp >= 0) {                                                                          \
                             GS2D_BWD_LDS_ACCUM(J, tot)                                                                \
                         }                                                                                             \
@@ -1028,6 +1229,19 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                     g[15] = d_op;                                                                                     \
                     /* each row reduces ITS splat into the splat's LDS accumulators */                                \
                     GS2D_EXP_BUTTERFLY                                                                                \
+                    if (NG == 8) { /* two values per lane: component half_idx (always an accumulator) and 8 + half_idx */ \
+                        float tot2;                                                                                   \
+                        if (ANY_DN) { g[12] = d_w * dn0; g[13] = d_w * dn1; g[14] = d_w * dn2; }                      \
+                        else { g[12] = 0.f; g[13] = 0.f; g[14] = 0.f; }                                               \
+                        reduce16_half(g, lane, tot, tot2);                                                            \
+                        tot = merge_twin_halves(tot, twin_m_ & lo_half_m, twin_m_ & ~lo_half_m);                      \
+                        tot2 = merge_twin_halves(tot2, twin_m_ & lo_half_m, twin_m_ & ~lo_half_m);                    \
+                        GS2D_BWD_LDS_ACCUM(J, tot)                                                                    \
+                        if (acc_comp_hi >= 0) {                                                                       \
+                            GS2D_BWD_LDS_ACCUM2(J, tot2)                                                              \
+                        } else if (ANY_DN && tot2 != 0.f) /* components 12-14 = the normal: record words 3-5 */       \
+                            atomicAdd(grad_rec + (size_t)(wb.pn[J] & 0x0FFFFFFFu) * GS2D_GRAD_FLOATS + (half_idx - 1), tot2); \
+                    } else {                                                                                          \
                     if (ANY_DN) {                                                                                     \
                         g[12] = d_w * dn0; g[13] = d_w * dn1; g[14] = d_w * dn2;                                      \
                         tot = reduce16_row(g, lane);                                                                  \
@@ -1044,15 +1258,16 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                     } else if (ANY_DN && tot != 0.f)                                                                  \
                         atomicAdd(grad_rec + (size_t)(wb.pn[J] & 0x0FFFFFFFu) * GS2D_GRAD_FLOATS + (slot - 9), tot); \
                     }                                                                                                 \
+                    }                                                                                                 \
                     if (ballot64(d_t != 0.f) != 0) {                                                                  \
-                        const float g_mx = row_sum_to_lane15(d_t * d0);                                               \
-                        const float g_my = row_sum_to_lane15(d_t * d1);                                               \
+                        const float g_mx = NG == 8 ? half_sum_to_lane7(d_t * d0) : row_sum_to_lane15(d_t * d0);       \
+                        const float g_my = NG == 8 ? half_sum_to_lane7(d_t * d1) : row_sum_to_lane15(d_t * d1);       \
                         if (DET) {                                                                                    \
                             _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++)                                          \
                                 if (row == r_ && li == 15 && (g_mx != 0.f || g_my != 0.f)) {                          \
                                     wb.acc()[J * NACC + 16] += g_mx; wb.acc()[J * NACC + 17] += g_my;                   \
                                 }                                                                                     \
-                        } else if (li == 15 && (g_mx != 0.f || g_my != 0.f)) {                                        \
+                        } else if ((NG == 8 ? (li & 7) == 7 : li == 15) && (g_mx != 0.f || g_my != 0.f)) {            \
                             float* dst = POSE ? dense_m2d + (size_t)(wb.pn[J] & 0x0FFFFFFFu) * 2                      \
                                               : grad_rec + (size_t)(wb.pn[J] & 0x0FFFFFFFu) * GS2D_GRAD_FLOATS + 16;  \
                             atomicAdd(dst, g_mx); atomicAdd(dst + 1, g_my);                                           \
@@ -1061,11 +1276,12 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                 }                                                                                                     \
             }                                                                                                         \
             J = jnn;                                                                                                  \
+            FJ_ = fnn_;                                                                                               \
             if (++t >= trips) break;                                                                                  \
         }
         for (;;) {
-            GS2D_BWD_STEP(ga0, ga1, ga2, j, gb0, gb1, gb2, jx)
-            GS2D_BWD_STEP(gb0, gb1, gb2, jx, ga0, ga1, ga2, j)
+            GS2D_BWD_STEP(ga0, ga1, ga2, j, gb0, gb1, gb2, jx, fj)
+            GS2D_BWD_STEP(gb0, gb1, gb2, jx, ga0, ga1, ga2, j, fjx)
         }
 #undef GS2D_BWD_STEP
         // flush: every touched splat of the batch goes to its global record once, four splats (one per row) per pass

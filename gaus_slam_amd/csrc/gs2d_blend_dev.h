@@ -49,3 +49,15 @@ __device__ unsigned long long g_wave_prof[2][4 * 8192 * 4];
 #ifdef GS2D_EXPERIMENT
 #define GS2D_BWD_LDS_ACCUM(JJ, V) if ((V) != 0.f) GS2D_EXP_LDSADD(&wb.acc()[((JJ) & 63) * NACC + acc_comp], V);
 #endif
+
+// dev A/B switches of round 4 (scripts/dev/variants.sh): GS2D_DEV_NO_CLASH = never take the LDS-atomic path of the accumulate
+// (WRONG results where two groups meet on a splat: prices the atomics); GS2D_DEV_LDS_PAD = extra bytes of LDS per workgroup of
+// blend_bwd (prices the occupancy cliff by itself)
+#ifdef GS2D_DEV_NO_CLASH
+#define GS2D_DEV_CLASH(X) false
+#else
+#define GS2D_DEV_CLASH(X) (X)
+#endif
+#ifndef GS2D_DEV_LDS_PAD
+#define GS2D_DEV_LDS_PAD 0
+#endif

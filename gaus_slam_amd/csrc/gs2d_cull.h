@@ -110,6 +110,21 @@ __device__ __forceinline__ uint32_t rows_from_groups(uint32_t g16)
 {
     return ((g16 & 0x0033u) ? 1u : 0u) | ((g16 & 0x00CCu) ? 2u : 0u) | ((g16 & 0x3300u) ? 4u : 0u) | ((g16 & 0xCC00u) ? 8u : 0u);
 }
+// EXPERIMENT builds with eight backward queues per wave (-DGS2D_BWD_GROUPS=8 / -DGS2D_BWD_POSE_GROUPS=8, see gs2d_blend.hip and
+// profiles/bwd_queue_ab_r04.txt) store eight HALF-ROW bits per quadrant instead: from its sixteen group bits (bit 4 gy + gx).  The backward's 4x4 sub-block r = 2 ry + rx
+// (one per 16-lane DPP row) covers group columns 2rx, 2rx+1 and group rows 2ry, 2ry+1; its half h (4x2 pixels, the 8 lanes of
+// half a DPP row) is group row 2ry + h.  Bit 2r + h.  The four ROW bits of the 4-queue backward are the ORs of the pairs
+// (rows_from_halfrows).
+__device__ __forceinline__ uint32_t halfrows_from_groups(uint32_t g16)
+{
+    return ((g16 & 0x0003u) ? 0x01u : 0u) | ((g16 & 0x0030u) ? 0x02u : 0u) | ((g16 & 0x000Cu) ? 0x04u : 0u) | ((g16 & 0x00C0u) ? 0x08u : 0u) |
+           ((g16 & 0x0300u) ? 0x10u : 0u) | ((g16 & 0x3000u) ? 0x20u : 0u) | ((g16 & 0x0C00u) ? 0x40u : 0u) | ((g16 & 0xC000u) ? 0x80u : 0u);
+}
+__device__ __forceinline__ uint32_t rows_from_halfrows(uint32_t h8)
+{
+    const uint32_t t = h8 | (h8 >> 1);  // bit 2r: row r
+    return (t & 1u) | ((t >> 1) & 2u) | ((t >> 2) & 4u) | ((t >> 3) & 8u);
+}
 
 #ifndef GS2D_CULL_T
 #define GS2D_CULL_T 256
@@ -139,8 +154,13 @@ __device__ __forceinline__ void cull_tile_list(const uint2 range, float tx0, flo
         const float nrho = reinterpret_cast<const float*>(np)[18];
         const uint64_t m64 = splat_touch_mask64(r0, r1, r2, rho_max, tx0, ty0);
         hits[i] = m64;
+#if GS2D_HALFROW_BITS
+        hits4[i] = halfrows_from_groups((uint32_t)m64 & 0xFFFFu) | (halfrows_from_groups((uint32_t)(m64 >> 16) & 0xFFFFu) << 8) |
+                   (halfrows_from_groups((uint32_t)(m64 >> 32) & 0xFFFFu) << 16) | (halfrows_from_groups((uint32_t)(m64 >> 48)) << 24);
+#else
         hits4[i] = rows_from_groups((uint32_t)m64 & 0xFFFFu) | (rows_from_groups((uint32_t)(m64 >> 16) & 0xFFFFu) << 8) |
                    (rows_from_groups((uint32_t)(m64 >> 32) & 0xFFFFu) << 16) | (rows_from_groups((uint32_t)(m64 >> 48)) << 24);
+#endif
         i += GS2D_CULL_T;
         if (i >= range.y) break;
         r0 = n0; r1 = n1; r2 = n2; rho_max = nrho; id_next = id_next2;

@@ -41,7 +41,7 @@ det_reduce_kernel(int P, const uint32_t* __restrict__ tiles_touched, const uint3
         const uint32_t i = inv[start + u];
         const uint32_t h = hits[i];
         for (int q = 0; q < 4; q++) {
-            if (((h >> (8 * q)) & 0xFu) == 0u) continue;  // that quadrant never staged this instance
+            if (((h >> (8 * q)) & 0xFFu) == 0u) continue;  // that quadrant never staged this instance (8 half-row bits per quadrant)
             const float* row = det_slots + ((size_t)i * 4 + q) * GS2D_GRAD_FLOATS;
 #pragma unroll
             for (int c = 0; c < 18; c++) sum[c] += row[c];

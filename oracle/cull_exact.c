@@ -17,7 +17,11 @@ static inline int passes(const float* T, float opa, float px, float py, float mx
     float a = fminf(0.99f, opa * expf(-0.5f * rho));
     return a >= 1.0f / 255.0f;
 }
-/* exact 16 sub-block bits per instance in the library's layout (byte q, bit r) */
+/* exact 16 sub-block bits per instance in the library's layout (byte q = quadrant, bit r = its 4x4 sub-block r).
+ * halfrows != 0: the layout of the eight-queue experiment builds instead (bit 2 r + h = half h, pixel rows 2h and 2h+1, of
+ * sub-block r; gs2d_cull.h halfrows_from_groups) */
+static int g_halfrows = 0;
+void exact_set_halfrows(int on) { g_halfrows = on; }
 void exact_bits(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D, const float* tm,
                 const float* normal_opacity, uint32_t* out)
 {
@@ -31,8 +35,8 @@ void exact_bits(int W, int H, const uint32_t* ranges, const uint32_t* point_list
                 int px = tx * 16 + x, py = ty * 16 + y;
                 if (px >= W || py >= H) continue;
                 if (passes(tm + 9 * id, normal_opacity[4 * id + 3], (float)px, (float)py, means2D[2 * id], means2D[2 * id + 1])) {
-                    int q = (y >> 3) * 2 + (x >> 3), r = ((y & 7) >> 2) * 2 + ((x & 7) >> 2);
-                    bits |= 1u << (8 * q + r);
+                    int q = (y >> 3) * 2 + (x >> 3), r = ((y & 7) >> 2) * 2 + ((x & 7) >> 2), h = ((y & 3) >> 1);
+                    bits |= g_halfrows ? 1u << (8 * q + 2 * r + h) : 1u << (8 * q + r);
                 }
             }
             out[j] = bits;

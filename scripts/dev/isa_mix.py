@@ -15,8 +15,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gaus_slam_amd", "csrc", "gs2d_blend.hip")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17"]
+SRC = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else os.path.join(ROOT, "gaus_slam_amd", "csrc", "gs2d_blend.hip")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17"] + [a for a in sys.argv[1:] if a.startswith("-")]
 
 
 def classify(op):
@@ -70,8 +70,8 @@ def main():
         src = open(out).read()
     print(f"# ISA instruction mix of {os.path.relpath(SRC, ROOT)} (hipcc {' '.join(FLAGS)})")
     for kname, title in (("blend_fwd_kernelILb1ELb0E", "blend_fwd_kernel<USE_SA=true, BATCH=false>"),
-                         ("blend_bwd_kernelILb1ELb0ELb0ELb0E", "blend_bwd_kernel<USE_SA=true, DET=false, BATCH=false, POSE=false>"),
-                         ("blend_bwd_kernelILb1ELb0ELb0ELb1E", "blend_bwd_kernel<USE_SA=true, DET=false, BATCH=false, POSE=true> (tracking)")):
+                         ("blend_bwd_kernelILb1ELb0ELb0ELb0ELi", "blend_bwd_kernel<USE_SA=true, DET=false, BATCH=false, POSE=false>"),
+                         ("blend_bwd_kernelILb1ELb0ELb0ELb1ELi", "blend_bwd_kernel<USE_SA=true, DET=false, BATCH=false, POSE=true> (tracking)")):
         m = re.search(r"\n(_ZN\S*" + kname + r"\S*):[^\n]*\n(.*?)s_endpgm", src, re.S)
         body = m.group(2)
         ops, labels = [], {}
@@ -92,7 +92,8 @@ def main():
             f = lambda k: (re.search(r"\." + k + r":\s+(\d+)", meta[0]) or [None, "?"])[1]
             info = (f", {f('vgpr_count')} VGPRs, {f('vgpr_spill_count')} spilled, scratch {f('private_segment_fixed_size')} B, "
                     f"LDS {f('group_segment_fixed_size')} B")
-        print(f"\n{title}: {len(ops)} instructions in the kernel{info}")
+        ng = re.search(r"Li(\d)E", m.group(1)[m.group(1).find(kname) + len(kname) - 2:])
+        print(f"\n{title}{' [' + ng.group(1) + ' queues per wave]' if ng and 'bwd' in kname else ''}: {len(ops)} instructions in the kernel{info}")
         q = [i for i, o in enumerate(names) if o == "ds_read_u8"]
         # the body without normal-channel gradients comes last in the backward; the forward has one body.  Each body has
         # two prologue queue reads and one per unrolled step: step A = [read A, read B), step B = [read B, back edge]

@@ -1,0 +1,18 @@
+set -e
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/r04l
+mkdir -p $OUT
+rm -f $OUT/ab.txt
+GS2D_LIB_PATH=$PWD/scripts/dev/variants/libng4lc.so timeout -k 10 900 python -m pytest tests/test_tracking.py tests/test_gpu_round3.py tests/test_gpu_parity.py tests/test_gpu_batch.py -x -q -m gpu -k "not build_info" > $OUT/pytest_ng4lc.log 2>&1 || { tail -40 $OUT/pytest_ng4lc.log; exit 1; }
+tail -2 $OUT/pytest_ng4lc.log
+for rep in 1 2 3; do
+for v in product ng4lc; do
+  if [ $v = product ]; then unset GS2D_LIB_PATH; else export GS2D_LIB_PATH=$PWD/scripts/dev/variants/lib$v.so; fi
+  timeout -k 10 200 python scripts/dev/stage_ms.py 1 >> $OUT/ab.txt 2>&1
+done
+done
+for v in product ng4lc; do
+  if [ $v = product ]; then unset GS2D_LIB_PATH; else export GS2D_LIB_PATH=$PWD/scripts/dev/variants/lib$v.so; fi
+  timeout -k 10 200 python scripts/dev/stage_ms.py 1 --workload tracking >> $OUT/ab.txt 2>&1
+done
+cat $OUT/ab.txt
