@@ -1,0 +1,58 @@
+"""Round-4 GPU tests: invariants of the backward's queues that round 3 only met by accident."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("use_sa", [True, False])
+@pytest.mark.parametrize("W,H", [(64, 48), (37, 21)])
+def test_backward_with_exhausted_rows_beside_live_ones(oracle, use_sa, W, H):
+    """The single-frame backward keeps one queue per 4x4 sub-block (DPP row) of a quadrant; a row whose queue is exhausted keeps
+    evaluating the batch's deepest staged record with all its lanes inactive while the other rows work on (gs2d_blend.hip,
+    BwdBatchT).  Round 3's abort (an exhausted row read past the staged records and corrupted a Gaussian id) was only caught by
+    a batch test; this scene forces the situation in the plain single-frame path: every splat is small and sits in the TOP-LEFT
+    4x4 sub-block of its 8x8 quadrant, so rows 1-3 of nearly every quadrant are exhausted from the first trip on while row 0
+    has many -- plus a few large splats so that some batches do fill all rows, and a ragged image whose border quadrants have
+    rows and lanes outside the picture.  Gradients against the oracle; a fault or a NaN fails it."""
+    rng = np.random.default_rng(7)
+    P = 3000
+    sc = util.make_scene(P, W, H, seed=51, regime="tracking", cull_frac=0.0)
+    cam = sc["cam"]
+    f, cx, cy = float(cam.K[0, 0]), float(cam.K[0, 2]), float(cam.K[1, 2])
+    z = rng.uniform(1.0, 4.0, P)
+    # pixel centres inside the top-left sub-block of a random quadrant
+    u = rng.integers(0, (W + 7) // 8, P) * 8 + rng.uniform(0.8, 2.2, P)
+    v = rng.integers(0, (H + 7) // 8, P) * 8 + rng.uniform(0.8, 2.2, P)
+    means = np.stack([(u - cx) / f * z, (v - cy) / f * z, z], 1)
+    sigma_px = np.where(rng.uniform(size=P) < 0.004, rng.uniform(3.0, 6.0, P), rng.uniform(0.3, 0.6, P))  # a dozen large splats
+    sc["means3D"] = torch.from_numpy(means).float()
+    sc["scales"] = torch.from_numpy(np.stack([z / f * sigma_px, z / f * sigma_px], 1)).float()
+    sc["rotations"] = torch.tensor([[0.0, 1.0, 0.0, 0.0]]).repeat(P, 1)  # normals facing the camera
+    sc["opacities"] = torch.from_numpy(rng.uniform(0.05, 0.6, (P, 1))).float()
+    oracle.set_threads(os.cpu_count() or 1)
+    o = util.oracle_forward(oracle, sc, use_sa=use_sa)
+    h = util.hip_forward(sc, use_sa=use_sa)
+    np.testing.assert_array_equal(h["point_list"], o["point_list"])
+    # the situation is really there: most pixels outside the top-left sub-blocks have no contributor, those inside have many
+    last = o["n_contrib"][:H * W].reshape(H, W)
+    ys, xs = np.mgrid[0:H, 0:W]
+    inside = ((xs % 8) < 4) & ((ys % 8) < 4)
+    assert np.median(last[inside]) >= 8
+    if W == 64:  # (the small ragged image is covered by its few large splats; it is there for the lanes outside the picture)
+        assert (last[~inside] == 0).mean() > 0.25
+    stable = (o["stability"] > 2e-5).reshape(H, W)
+    dc, da = util.make_upstream_grads(W, H, channels=(0, 1, 2, 3, 4, 5, 6))
+    dc, da = (dc * W * H).numpy(), (da * W * H).numpy()
+    dc[:, ~stable] = 0; da[:, ~stable] = 0
+    go = oracle.backward(o, dc, da)
+    gh = util.hip_backward(h, dc, da)
+    oracle.set_threads(1)
+    for k in ("dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dtransMat", "dL_dscales", "dL_drotations", "dL_dmeans2D"):
+        assert np.isfinite(gh[k]).all(), k
+        assert util.grad_err(gh[k], go[k].reshape(gh[k].shape)) <= 1e-4, (k, util.grad_err(gh[k], go[k].reshape(gh[k].shape)))
