@@ -312,7 +312,7 @@ int fwd_validate(const FwdShared& c)
 static int nap_wait_default() { const char* e = getenv("GS2D_NAP_WAIT"); return (e && e[0] == '0') ? 0 : 1; }
 std::atomic<int> g_nap_wait{nap_wait_default()};
 #ifndef GS2D_NAP_MARGIN_US
-#define GS2D_NAP_MARGIN_US 110.0
+#define GS2D_NAP_MARGIN_US 150.0
 #endif
 thread_local double g_wait_mean_us = 0.0;
 
@@ -333,8 +333,11 @@ bool wait_total(FwdFrame& f, hipStream_t s, bool may_nap = false)
                 return hipStreamSynchronize(s) == hipSuccess && *f.pinned != 0xFFFFFFFFu;
         }
         const double w = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        // running mean of the waits that did NOT oversleep much; an overslept one (w far above the mean) pulls it up slowly only
-        g_wait_mean_us = g_wait_mean_us == 0.0 ? w : 0.9 * g_wait_mean_us + 0.1 * (w < 2.0 * g_wait_mean_us + 50.0 ? w : g_wait_mean_us);
+        // running mean of the waits; one wait counts for at most twice the mean + 50 us, so that a single overslept or
+        // disturbed wait cannot make the next ones oversleep, while a lasting change (the first steps of a loop find an idle
+        // GPU, the later ones a full queue) still pulls the mean up by 10 % per step
+        const double wc = w < 2.0 * g_wait_mean_us + 50.0 ? w : 2.0 * g_wait_mean_us + 50.0;
+        g_wait_mean_us = g_wait_mean_us == 0.0 ? wc : 0.9 * g_wait_mean_us + 0.1 * wc;
         return true;
     }
     while (*f.pinned == 0xFFFFFFFFu) {
