@@ -736,7 +736,7 @@ __device__ __forceinline__ float half_sum_to_lane7(float v)
        chain per trip */                                                                                                \
     /* eight queues: per LANE instead (the flag rides in bit 6 of the queue entry, see the queue build): with eight queues   \
        some two of them meet in a good share of the trips, and an LDS float atomic costs by the lane */               \
-    const bool clash_ = GS2D_DEV_CLASH(LANE_CLASH ? __builtin_amdgcn_inverse_ballot_w64(FJ_) : ((clash_mask >> t) & 1ull) != 0ull);
+    const bool clash_ = GS2D_DEV_CLASH(ROW_ACC ? false : LANE_CLASH ? __builtin_amdgcn_inverse_ballot_w64(FJ_) : ((clash_mask >> t) & 1ull) != 0ull);
 #ifndef GS2D_BWD_LDS_ACCUM  // (gs2d_blend_dev.h may have replaced it in an experiment build)
 #define GS2D_BWD_LDS_ACCUM(JJ, V)                                                                                       \
     if ((V) != 0.f) {                                                                                                   \
@@ -769,6 +769,7 @@ __device__ __forceinline__ float half_sum_to_lane7(float v)
 #define GS2D_ACC 13
 #define GS2D_ACC_DET 18
 #define GS2D_ACC_POSE 3   // pose-only backward: dT[2], dT[5], dT[8] -- all dL/dmean needs (gs2d_preprocess.hip, backward.cu:637-663)
+#define GS2D_ACC_POSE_ROWS (4 * GS2D_ACC_POSE)  // ... kept once per ROW of the wave (see ROW_ACC in blend_bwd_kernel)
 template <int NACC, int NQ = 4>
 struct BwdBatchT {
     // Entries past a queue's end hold slot 63 -- the deepest staged splat, always a real record -- and a row is live while the
@@ -812,9 +813,14 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     static_assert(!(POSE && (DET || BATCH)), "the pose-only backward is single-frame and non-deterministic");
     static_assert(NG == 4 || (NG == 8 && !DET), "queues per wave: 4, or 8 in the non-deterministic kernels");
     // the LDS-atomic fallback of the accumulate decided per LANE (flag in bit 6 of the queue entry) instead of per trip
-    constexpr bool LANE_CLASH = NG == 8 || (GS2D_BWD_LANE_CLASH && !DET && !POSE);
-    constexpr int NACC = DET ? GS2D_ACC_DET : (POSE ? GS2D_ACC_POSE : GS2D_ACC);
+
+    // POSE: three sums per (row, splat) are so few that every ROW of the wave can keep accumulators of its own (4 x 3 per staged
+    // splat, less LDS than the full kernel's 13): two rows never meet on an address, so the accumulate is a plain read / add /
+    // store in every trip -- no LDS float atomic anywhere in the kernel; the flush adds a splat's four row sums up.
+    constexpr bool ROW_ACC = POSE;
+    constexpr int NACC = DET ? GS2D_ACC_DET : (POSE ? GS2D_ACC_POSE_ROWS : GS2D_ACC);
     typedef BwdBatchT<NACC, NG> BwdBatch;
+    constexpr bool LANE_CLASH = !ROW_ACC && (NG == 8 || (GS2D_BWD_LANE_CLASH && !DET));
     // (a byte array of exactly 4 x BYTES: the eight-queue struct is declared with a one-word `tail` it never touches, the
     // allocation ends with its last queue)
     __shared__ __attribute__((aligned(16))) unsigned char batch_mem[4 * BwdBatch::BYTES + GS2D_DEV_LDS_PAD];
@@ -926,8 +932,10 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     // accumulator (0-7), the second one of 8-11, a normal component (12-14) or the opacity (15 -> accumulator 12);
     // POSE: reduce3_half leaves -dk.z in lanes 0-3 of a half, -dl.z in lanes 4-7, Tw.z everywhere: lanes 0, 4 and 2 add them up
     const int half_idx = reduce16_half_index(lane);
-    const int acc_comp = NG == 8 ? (POSE ? ((li & 7) == 0 ? 0 : ((li & 7) == 4 ? 1 : ((li & 7) == 2 ? 2 : -1))) : half_idx)
-                       : POSE ? (li == 0 ? 0 : (li == 8 ? 1 : (li == 4 ? 2 : -1)))
+    const int pose_comp = NG == 8 ? ((li & 7) == 0 ? 0 : ((li & 7) == 4 ? 1 : ((li & 7) == 2 ? 2 : -1)))
+                                  : (li == 0 ? 0 : (li == 8 ? 1 : (li == 4 ? 2 : -1)));
+    const int acc_comp = POSE ? (pose_comp < 0 ? -1 : row * GS2D_ACC_POSE + pose_comp)  // (this row's own three accumulators)
+                       : NG == 8 ? half_idx
                               : (slot < 12 ? slot : (slot == 15 ? 12 : (DET ? slot + 1 : -1)));
     const int acc_comp_hi = half_idx < 4 ? 8 + half_idx : (half_idx == 7 ? 12 : -1);  // NG == 8, full kernel: the second value
     const uint64_t lo_half_m = ballot64((li & 8) == 0);                               // lanes of the lower halves of the rows
@@ -1302,15 +1310,17 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                 }
             }
         } else if (POSE) {
-            // sixteen splats per pass: lane l flushes accumulator (l & 3) of slot f0 + l / 4 into the dense float4 of its Gaussian
+            // sixteen splats per pass: lane l adds up the four rows' accumulators (l & 3) of slot f0 + l / 4 and flushes the sum
+            // into the dense float4 of its Gaussian
             for (int f0 = 64 - fill; f0 < 64; f0 += 16) {
                 const int fs = f0 + (lane >> 2), c = lane & 3;
                 if (fs < 64 && c < GS2D_ACC_POSE) {
-                    float* pa = &wb.acc()[fs * GS2D_ACC_POSE + c];
-                    const float va = *pa;
-                    if (va != 0.f) {
-                        *pa = 0.f;
-                        atomicAdd(grad_rec + (size_t)(wb.pn[fs] & 0x0FFFFFFFu) * 4 + c, va);
+                    float* pa = &wb.acc()[fs * GS2D_ACC_POSE_ROWS + c];
+                    const float v0 = pa[0], v1 = pa[GS2D_ACC_POSE], v2 = pa[2 * GS2D_ACC_POSE], v3 = pa[3 * GS2D_ACC_POSE];
+                    const float va = (v0 + v1) + (v2 + v3);
+                    if (v0 != 0.f || v1 != 0.f || v2 != 0.f || v3 != 0.f) {
+                        pa[0] = 0.f; pa[GS2D_ACC_POSE] = 0.f; pa[2 * GS2D_ACC_POSE] = 0.f; pa[3 * GS2D_ACC_POSE] = 0.f;
+                        if (va != 0.f) atomicAdd(grad_rec + (size_t)(wb.pn[fs] & 0x0FFFFFFFu) * 4 + c, va);
                     }
                 }
             }

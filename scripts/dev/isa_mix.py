@@ -3,8 +3,8 @@
 LDS / VMEM / waitcnt / nop per loop TRIP (one unrolled step of the software-pipelined trip loop), per staged CHUNK
 (staging loop body) and per FLUSH pass (backward only), for the shipped source.  Output kept as profiles/isa_mix_rNN.txt.
 
-Regions are located by anchors in the linear ISA: a backward trip step is the code between two consecutive LDS
-accumulates, the forward's trip loop (two unrolled trips) the smallest loop around its last three `v_exp_f32`; the staging chunk is the loop body around the cull-bit byte load
+Regions are located by anchors in the linear ISA: a backward trip step is the code between two consecutive queue
+reads (`ds_read_u8`), the forward's trip loop (two unrolled trips) the smallest loop around its last three `v_exp_f32`; the staging chunk is the loop body around the cull-bit byte load
 (`global_load_ubyte`); a flush pass is the loop body containing the gradient-record atomics (`global_atomic_add_f32`
 after the last trip step).  usage: isa_mix.py [path/to/gs2d_blend.hip]"""
 import collections
@@ -104,9 +104,8 @@ def main():
             if op.startswith(("s_cbranch", "s_branch")) and arg in labels and labels[arg] <= rA:
                 back = i
                 break
-        if "bwd" in kname:  # one LDS accumulate per step: the cleanest anchor of the backward's two unrolled steps
-            da = [i for i, o in enumerate(names) if o == "ds_add_f32"]
-            print(fmt("trip step (between LDS accumulates)", names[da[-2]:da[-1]]))
+        if "bwd" in kname:  # one queue read (ds_read_u8) per step: the anchor of the backward's two unrolled steps
+            print(fmt("trip step (between queue reads)", names[rA:rB]))
         else:
             # the forward's two unrolled steps share their queue reads' positions with the record reads, so the loop as a whole
             # is the unit: the smallest loop that contains the last three v_exp_f32 (two alpha exponentials + a confidence one)
