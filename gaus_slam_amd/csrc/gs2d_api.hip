@@ -940,7 +940,7 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         if (R > 0) {
             g_timer.begin(ST_BLEND_BWD, s);
             const gs2d::BlendBwdFrame bf = {ranges, point_list, rec, pix_state, hits, dL_dpix, dL_depths, grad_rec, nullptr,
-                                            pose_fast ? grad_rec + 4 * (size_t)P : nullptr};
+                                            (const uint16_t*)(binning_buffer + BL.hits), pose_fast ? grad_rec + 4 * (size_t)P : nullptr};
             gs2d::launch_blend_bwd(width, height, 1, &bf, background, use_sa, dL_dpose, pose_floats, s);
             g_timer.end(ST_BLEND_BWD, s);
             GS2D_STAGE("blend_bwd");
@@ -954,7 +954,8 @@ int gs2d_backward_staged(int stages, int g_begin, int g_end, int P, int D, int M
         g_timer.begin(ST_BLEND_BWD, s);
         if (R > 0) {
             GS2D_CHECK(hipMemsetAsync(det_slots, 0, sizeof(float) * GS2D_GRAD_FLOATS * 4 * (size_t)R, s), "memset det_slots");
-            const gs2d::BlendBwdFrame bf = {ranges, point_list, rec, pix_state, hits, dL_dpix, dL_depths, grad_rec, det_slots, nullptr};
+            const gs2d::BlendBwdFrame bf = {ranges, point_list, rec, pix_state, hits, dL_dpix, dL_depths, grad_rec, det_slots,
+                                            (const uint16_t*)(binning_buffer + BL.hits), nullptr};
             gs2d::launch_blend_bwd(width, height, 1, &bf, background, use_sa, nullptr, 0, s);
         }
         gs2d::launch_det_reduce(P, R, width, height, ranges, point_list, (const ushort4*)(geom_buffer + GL.rect),
@@ -1033,6 +1034,7 @@ int gs2d_backward_batch(int K, const gs2d_frame_grad* fr, int accumulate, int P,
             b.pix_state = (const float*)(f.img_buffer + IL.pix);
             b.hits = (const uint8_t*)(f.binning_buffer + BL.hits4);
             b.dL_dpix = f.dL_dpix; b.dL_dothers = f.dL_depths; b.grad_rec = grad_rec; b.det_slots = nullptr; b.dense_m2d = nullptr;
+            b.hits16 = (const uint16_t*)(f.binning_buffer + BL.hits);
         }
     }
     if (nb > 0) {

@@ -24,10 +24,12 @@
 #define GS2D_BWD_GROUPS 4       // queues per wave of the full backward: 4 (one per 4x4 sub-block = DPP row) or 8 (one per 4x2 half-row)
 #endif
 #ifndef GS2D_BWD_POSE_GROUPS
-#define GS2D_BWD_POSE_GROUPS 4  // ... of the pose-only backward
+#define GS2D_BWD_POSE_GROUPS 8  // ... of the pose-only backward (its accumulators are per row: no LDS atomics to eat the trips
+                                // eight queues save; it derives its half-row cull bits from the forward's group bits itself)
 #endif
-// eight queues anywhere: the forward's phase 0 stores eight half-row cull bits per (instance, quadrant) instead of four row bits
-#define GS2D_HALFROW_BITS (GS2D_BWD_GROUPS == 8 || GS2D_BWD_POSE_GROUPS == 8)
+// eight queues in the FULL backward (experiment builds): the forward's phase 0 stores eight half-row cull bits per (instance,
+// quadrant) instead of four row bits
+#define GS2D_HALFROW_BITS (GS2D_BWD_GROUPS == 8)
 #ifndef GS2D_BWD_LANE_CLASH
 #define GS2D_BWD_LANE_CLASH 1   // four queues, full backward: the LDS-atomic fallback of the accumulate is decided per LANE (a flag in
                                 // bit 6 of the queue entry) instead of per trip: 0.2385 -> 0.2331 ms (profiles/bwd_queue_ab_r04.txt);
@@ -838,6 +840,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     const float4* __restrict__ rec = fa->rec;
     const float* __restrict__ pix_state = fa->pix_state;
     const uint8_t* __restrict__ hits = fa->hits;
+    const uint16_t* __restrict__ hits16 = fa->hits16;
     const float* __restrict__ dL_dpix = fa->dL_dpix;
     const float* __restrict__ dL_dothers = fa->dL_dothers;
     float* __restrict__ grad_rec = fa->grad_rec;
@@ -852,6 +855,11 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     const int row = lane >> 4, li = lane & 15;                       // DPP row = 4x4 sub-block (same mapping as the forward)
     const int grp = NG == 8 ? lane >> 3 : row;                       // the queue this lane follows (NG == 8: lanes 0-7 of a row =
     const int grp8 = grp * 8;                                        // its pixel rows 0-1, lanes 8-15 = pixel rows 2-3)
+    // the cull bits of list position `at` for this quadrant, in the form this instantiation's queues want
+    auto cull_bits = [&](uint32_t at) -> uint32_t {
+        if (NG == 8 && !GS2D_HALFROW_BITS) return halfrows_from_groups_fast(hits16[(size_t)at * 4 + wave]);
+        return hits[(size_t)at * 4 + wave];
+    };
     const uint8_t* qrow = wb.ql[grp];
     const int px = qx0 + (row & 1) * 4 + (li & 3), py = qy0 + (row >> 1) * 4 + (li >> 2);
     const bool inside = px < W && py < H;
@@ -977,7 +985,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
         uint32_t pf_tm = 0u, pf_id = 0u;
         if (chunk >= 0) {
             const uint32_t at = min(range.x + (uint32_t)chunk * 64u + lane, last_i);
-            pf_tm = hits[(size_t)at * 4 + wave];
+            pf_tm = cull_bits(at);
             pf_id = point_list[at];  // unconditional and coalesced: issued together with the cull bits
         }
         for (;;) {
@@ -993,7 +1001,7 @@ blend_bwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
                 tm = lane < n ? ((NG == 8 || !GS2D_HALFROW_BITS) ? pf_tm : rows_from_halfrows(pf_tm)) : 0u;
                 my_id = pf_id;
                 const uint32_t nb = min(range.x + (uint32_t)max(chunk, 0) * 64u + lane, last_i);
-                pf_tm = hits[(size_t)nb * 4 + wave];
+                pf_tm = cull_bits(nb);
                 pf_id = point_list[nb];
             }
             const uint64_t tb = ballot64(tm != 0u);

@@ -312,6 +312,8 @@ struct BlendBwdFrame {
     const float* dL_dpix; const float* dL_dothers; float* grad_rec;
     float* det_slots;  // != nullptr selects the deterministic variant (single frame only): no atomics, per-(instance, quadrant)
                        // partial records (GS2D_GRAD_FLOATS floats each, R * 4 of them, zero-initialised by the caller)
+    const uint16_t* hits16;  // the forward's sixteen group bits per (instance, quadrant): the eight-queue pose-only kernel derives
+                             // its half-row bits from them (the other kernels read `hits`, the forward's four row bits)
     float* dense_m2d;  // != nullptr selects the POSE-ONLY variant (single frame, non-deterministic): grad_rec is then used as a
                        // dense float4[P] (dT[2], dT[5], dT[8], -) and dense_m2d as float2[P] dL_dmean2D.xy (both zero on entry)
 };
