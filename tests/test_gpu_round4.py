@@ -56,3 +56,30 @@ def test_backward_with_exhausted_rows_beside_live_ones(oracle, use_sa, W, H):
     for k in ("dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dtransMat", "dL_dscales", "dL_drotations", "dL_dmeans2D"):
         assert np.isfinite(gh[k]).all(), k
         assert util.grad_err(gh[k], go[k].reshape(gh[k].shape)) <= 1e-4, (k, util.grad_err(gh[k], go[k].reshape(gh[k].shape)))
+
+
+def test_launch_ahead_forward_zero_instances_and_jumps(oracle):
+    """The launch-ahead forward (gs2d_set_launch_ahead, default) sizes its grids and its binning chunk from the previous call's
+    count for the same problem shape and reads the count on the device.  Same shape, three very different counts in a row:
+    a regular scene, the same Gaussians all moved behind the camera (zero instances: every kernel behind the duplication runs
+    with R = 0 in a chunk sized for many), then huge splats (a count far beyond the capacity: those kernels do nothing, the host
+    runs the stages again).  Every call must give the oracle's lists and image."""
+    from gaus_slam_amd import rasterizer
+    assert rasterizer.is_launch_ahead()
+    W, H, P = 256, 192, 5000
+    base = util.make_scene(P, W, H, seed=61, regime="tracking")
+    gone = dict(base); gone["means3D"] = base["means3D"].clone(); gone["means3D"][:, 2] = -1.0   # behind the near plane
+    huge = dict(base); huge["scales"] = base["scales"] * 30.0
+    for name, sc in (("regular", base), ("nothing visible", gone), ("regular again", base), ("huge splats", huge), ("regular once more", base)):
+        o = util.oracle_forward(oracle, sc, use_sa=True)
+        h = util.hip_forward(sc, use_sa=True)
+        assert h["num_rendered"] == o["num_rendered"], name
+        if name == "nothing visible":
+            assert h["num_rendered"] == 0 and float(np.abs(h["color"]).max()) == 0.0 and float(np.abs(h["allmap"]).max()) == 0.0
+            continue
+        np.testing.assert_array_equal(h["point_list"], o["point_list"], err_msg=name)
+        np.testing.assert_array_equal(h["ranges"], o["ranges"], err_msg=name)
+        stable = (o["stability"] > 2e-5).reshape(H, W)
+        assert np.abs(h["color"] - o["color"])[:, stable].max() <= 1e-4, name
+        assert np.abs(h["allmap"] - o["allmap"])[:, stable].max() <= 1e-4, name
+    assert util.oracle_forward(oracle, huge, use_sa=True)["num_rendered"] > 8 * util.oracle_forward(oracle, base, use_sa=True)["num_rendered"]
