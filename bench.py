@@ -45,6 +45,8 @@ WORKLOADS = {  # name -> (W, H, P, regime)
     "op": (640, 480, 500000, "mapping"), "b200k": (640, 480, 200000, "mapping"), "replica": (1200, 680, 600000, "tracking"),
     "scannetpp": (1168, 876, 2000000, "mapping"), "scannetpp_ref": (876, 584, 2000000, "mapping"),
     "tracking": (640, 480, 500000, "tracking"), "mapping": (640, 480, 500000, "mapping"),
+    # the same two SLAM iterations at Replica's native frame size (configs/data/replica.yaml:3-4; BASELINE configs[2] / [3] run at it)
+    "tracking_replica": (1200, 680, 600000, "tracking"), "mapping_replica": (1200, 680, 600000, "mapping"),
 }
 
 
@@ -152,7 +154,7 @@ def main():
     W0, H0, P0, regime = WORKLOADS[args.workload]
     P, W, H = args.gaussians or P0, args.width or W0, args.height or H0
     use_sa = not args.no_sa
-    if args.workload in ("tracking", "mapping"):
+    if args.workload.startswith(("tracking", "mapping")):
         result = slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world)
     else:
         result = op_workload(args, dev, P, W, H, regime, use_sa, rank, world)
@@ -508,7 +510,8 @@ def slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world):
     g = torch.Generator().manual_seed(0)
     gt_color = torch.rand(H, W, 3, generator=g).to(dev)
     gt_depth = (0.5 + 5 * torch.rand(H, W, 1, generator=g)).to(dev)
-    if args.workload == "tracking":
+    is_tracking = args.workload.startswith("tracking")
+    if is_tracking:
         sc = make_scene(P, W, H, seed=0, regime="tracking")
         settings = gs_render.settings_from_camera(sc["cam"], dev, use_sa=use_sa)
         p = {k: sc[k].to(dev) for k in names}
@@ -575,13 +578,13 @@ def slam_iteration_workload(args, dev, P, W, H, use_sa, rank, world):
     from gaus_slam_amd import rasterizer
     with torch.no_grad():  # instances the iteration's render handles
         e = torch.empty(0, device=dev)
-        q = p if args.workload == "tracking" else leaves
-        kw = dict(pose_Rt=w2c[:3, :4].detach().contiguous()) if args.workload == "tracking" else {}
+        q = p if is_tracking else leaves
+        kw = dict(pose_Rt=w2c[:3, :4].detach().contiguous()) if is_tracking else {}
         R = rasterizer.rasterize_gaussians(settings.bg, q["means3D"], q["colors"], q["opacities"], q["scales"], q["rotations"], 1.0, e,
                                            settings.viewmatrix, settings.projmatrix, settings.tanfovx, settings.tanfovy, H, W, e, 0,
                                            settings.campos, use_sa, False, False, **kw)[0]
     roofline = build_roofline(args, dev, stage_ms, sc["means3D"].shape[0], R, H * W, elapsed / args.steps * 1e3,
-                              pose_only=args.workload == "tracking")
+                              pose_only=is_tracking)
     return {"metric": metric, "value": round(args.steps / elapsed, 3), "unit": "iterations/s", "n_gpus": 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
