@@ -229,21 +229,38 @@ radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __res
 constexpr int BIN_T = 256;
 constexpr int BIN_ITEMS = GS2D_BIN_ITEMS;   // instances per workgroup
 constexpr int BIN_WAVE_ITEMS = BIN_ITEMS / 4;
+#ifndef GS2D_DEV_BIN  // timing experiments only (wrong lists; always with 2): 1 no counter-table read, 2 linear stores, 4 no ranking, 8 no counting
+#define GS2D_DEV_BIN 0
+#endif
+
+// Which block of pairs a binning workgroup takes.  Workgroups go to the eight XCDs round robin and each XCD has its own L2; block
+// b's counter of tile t sits right behind block b - 1's, and so do their pairs of the tile in the output.  XCD x takes the blocks
+// [x per, (x + 1) per): the pieces of a cache line go through ONE L2 at about the same time.  Measured at 1168x876 / 2M:
+// bin_hist 17.5 -> 15.5 us (its 4-byte counters leave as lines); bin_scatter unchanged (an XCD's share of the output is as large
+// as its L2).  Returns -1 for the workgroups beyond the last block (the grid is rounded up to 8 per: bin_grid).
+__device__ __forceinline__ int bin_block_of(int wg, int nblocks)
+{
+    const int per = (nblocks + 7) >> 3;
+    const int b = (wg & 7) * per + (wg >> 3);
+    return (wg >> 3) < per && b < nblocks ? b : -1;
+}
 
 // hist[tile * nblocks + block].  ITEMS = instances per workgroup: BIN_ITEMS (4096) or a multiple of it.  Every workgroup
 // pays for the whole tile table (clearing, writing and later scanning `ntiles` counters), so with thousands of tiles a
-// 4096-pair workgroup spends more time on the table than on its pairs (ScanNet++ shape, 4015 tiles: 40 + 13 + 108 us for the
-// three passes): images of many tiles take larger workgroups (bin_items_for), a quarter of the counters and of the rows to scan.
+// 4096-pair workgroup spends more time on the table than on its pairs (ScanNet++ shape, 4015 tiles, round 3's kernels: 40 + 13 + 108 us
+// for the three passes): images of many tiles take larger workgroups (bin_items_for), a quarter of the counters and of the rows to scan.
 template <int ITEMS>
 __device__ __forceinline__ void
 bin_hist_body(const uint64_t* __restrict__ keys, int n, int ntiles, uint32_t* __restrict__ hist, int nblocks)
 {
+    const int blk = bin_block_of(blockIdx.x, nblocks);
+    if (blk < 0) return;
     extern __shared__ uint32_t lds[];  // [ntiles]
     for (int t = threadIdx.x; t < ntiles; t += BIN_T) lds[t] = 0;
     __syncthreads();
 #pragma unroll 1
     for (int sub = 0; sub < ITEMS / BIN_ITEMS; sub++) {
-        const int base = blockIdx.x * ITEMS + sub * BIN_ITEMS;
+        const int base = blk * ITEMS + sub * BIN_ITEMS;
         const int end = min(n, base + BIN_ITEMS);
         if (base >= end) break;
         // all loads in flight before the first LDS atomic: the kernel is latency-bound, not bandwidth-bound
@@ -258,7 +275,7 @@ bin_hist_body(const uint64_t* __restrict__ keys, int n, int ntiles, uint32_t* __
             if (tl[r] != 0xffffffffu) atomicAdd(&lds[tl[r]], 1u);
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < ntiles; t += BIN_T) hist[(size_t)t * nblocks + blockIdx.x] = lds[t];
+    for (int t = threadIdx.x; t < ntiles; t += BIN_T) hist[(size_t)t * nblocks + blk] = lds[t];
 }
 template <int ITEMS>
 __global__ void __launch_bounds__(BIN_T)
@@ -269,7 +286,6 @@ bin_hist_kernel(const uint64_t* __restrict__ keys, int n, int ntiles, uint32_t* 
 __global__ void __launch_bounds__(BIN_T) bin_hist_batch_kernel(int ntiles, const gs2d::BinFrames tab)
 {
     const gs2d::BinFrame& f = tab.f[blockIdx.y];
-    if ((int)blockIdx.x >= f.nblocks) return;  // the grid is sized for the frame with the most instances
     bin_hist_body<BIN_ITEMS>(f.keys_unsorted, f.R, ntiles, f.hist, f.nblocks);
 }
 
@@ -307,21 +323,37 @@ __global__ void __launch_bounds__(256) bin_row_scan_batch_kernel(int ntiles, con
 // ITEMS == BIN_ITEMS: each wave's 1024 pairs stay in registers between the counting and the scatter; larger ITEMS (images of
 // many tiles, see bin_hist_body): each wave owns ITEMS / 4 CONSECUTIVE pairs (so that (wave, position) order is element
 // order, which stability needs), counts them in rounds of 1024 and reads them a second time (cache-warm) to scatter.
+//
+// LDS: base[tile] (uint32: where this workgroup's pairs of the tile start) + one uint16 counter per (wave, tile) -- a wave owns
+// at most 4096 pairs -- two to a word: 12 bytes per tile (until round 4: 16, four uint32 running destinations; at 4015 tiles
+// that was 64 KB and two workgroups per CU).  The counter first counts the wave's pairs of the tile, then holds how many
+// pairs of the tile the waves before it own, then runs.
+// Rank of a pair among its wave's pairs of the same tile (round 4): the LDS atomic's return value.  Lanes of one instruction
+// that name the same tile are served in an order the hardware does not promise, so they are found (the counter moved by more
+// than one) and re-ranked in lane order, one ballot per distinct tile they share -- 1.6 such tiles per 64 pairs at 1200 tiles,
+// fewer at more.  Until round 4 every instruction paid a match-any over all tile bits (11-12 ballots, each a 64-bit select per
+// lane): 29 of bin_scatter's 93 us at 1168x876 / 2M (scripts/dev/binexp.sh).
 template <int ITEMS>
 __device__ __forceinline__ void
 bin_scatter_body(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
                  uint32_t* __restrict__ vals_out, int n, int ntiles, int nbits, const uint32_t* __restrict__ offs_excl,
                  const uint32_t* __restrict__ tile_total, int nblocks, uint2* __restrict__ ranges)
 {
-    extern __shared__ uint32_t lds[];  // [4][ntiles] per-wave counts, then running destinations
+    extern __shared__ uint32_t lds[];  // base[ntiles], then [4][nt2 / 2] words of uint16 counter pairs
+    // (no instances: the grid is one workgroup, which writes the empty tile ranges)
+    const int blk = nblocks > 0 ? bin_block_of(blockIdx.x, nblocks) : (blockIdx.x == 0 ? 0 : -1);
+    if (blk < 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int t = threadIdx.x; t < 4 * ntiles; t += BIN_T) lds[t] = 0;
+    const int nt2 = ntiles + (ntiles & 1);
+    uint32_t* const cnt_words = lds + ntiles;
+    for (int t = threadIdx.x; t < 2 * nt2; t += BIN_T) cnt_words[t] = 0;
     __syncthreads();
     constexpr int WAVE_SPAN = ITEMS / 4;           // consecutive pairs per wave
+    static_assert(WAVE_SPAN < 65536 && ITEMS < 65536, "uint16 counters");
     constexpr int ROUNDS = WAVE_SPAN / BIN_WAVE_ITEMS;  // rounds of 1024
-    const int wbeg0 = blockIdx.x * ITEMS + wave * WAVE_SPAN;
+    const int wbeg0 = blk * ITEMS + wave * WAVE_SPAN;
     const int wend0 = min(n, wbeg0 + WAVE_SPAN);
-    uint32_t* mine = lds + wave * ntiles;
+    uint32_t* const mine = cnt_words + wave * (nt2 >> 1);  // counter of tile d: half (d & 1) of mine[d >> 1]
     constexpr int PER_LANE = BIN_WAVE_ITEMS / 64;  // 16
     uint64_t k[PER_LANE];
     uint32_t v[PER_LANE];
@@ -339,8 +371,10 @@ bin_scatter_body(const uint64_t* __restrict__ keys_in, const uint32_t* __restric
             if (ROUNDS == 1) v[r] = i < wend ? vals_in[i] : 0u;
         }
 #pragma unroll
-        for (int r = 0; r < PER_LANE; r++)
-            if (wbeg + r * 64 + lane < wend) atomicAdd(&mine[(uint32_t)(k[r] >> 32)], 1u);
+        for (int r = 0; r < PER_LANE; r++) {
+            const uint32_t d = (uint32_t)(k[r] >> 32);
+            if (!(GS2D_DEV_BIN & 8) && wbeg + r * 64 + lane < wend) atomicAdd(&mine[d >> 1], 1u << (16 * (d & 1u)));
+        }
     }
     __syncthreads();
     {
@@ -351,18 +385,20 @@ bin_scatter_body(const uint64_t* __restrict__ keys_in, const uint32_t* __restric
         uint32_t mysum = 0;
         for (int t = t0; t < t1; t++) mysum += tile_total[t];
         uint32_t running = block_incl_scan(mysum, nullptr) - mysum;
+        uint16_t* const c16 = reinterpret_cast<uint16_t*>(cnt_words);
         for (int t = t0; t < t1; t++) {
             const uint32_t tot = tile_total[t];
-            const uint32_t c0 = lds[t], c1 = lds[ntiles + t], c2 = lds[2 * ntiles + t];
-            const uint32_t start = running + (nblocks > 0 ? offs_excl[(size_t)t * nblocks + blockIdx.x] : 0u);
-            lds[t] = start; lds[ntiles + t] = start + c0; lds[2 * ntiles + t] = start + c0 + c1; lds[3 * ntiles + t] = start + c0 + c1 + c2;
+            const uint32_t c0 = c16[t], c1 = c16[nt2 + t], c2 = c16[2 * nt2 + t];
+            lds[t] = running + (nblocks > 0 && !(GS2D_DEV_BIN & 1) ? offs_excl[(size_t)t * nblocks + blk] : 0u);
+            c16[t] = 0; c16[nt2 + t] = (uint16_t)c0; c16[2 * nt2 + t] = (uint16_t)(c0 + c1); c16[3 * nt2 + t] = (uint16_t)(c0 + c1 + c2);
             // tile ranges = boundaries of the scanned histogram (rasterizer_impl.cu:116-138 semantics)
-            if (blockIdx.x == 0) ranges[t] = tot ? make_uint2(running, running + tot) : make_uint2(0u, 0u);
+            if (blk == 0) ranges[t] = tot ? make_uint2(running, running + tot) : make_uint2(0u, 0u);
             running += tot;
         }
     }
     __syncthreads();
     const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    (void)nbits;
 #pragma unroll 1
     for (int rd = 0; rd < ROUNDS; rd++) {
         if (ROUNDS > 1) {  // second look at this round's pairs (the counting pass brought them into the caches)
@@ -376,24 +412,47 @@ bin_scatter_body(const uint64_t* __restrict__ keys_in, const uint32_t* __restric
                 v[r] = i < wend ? vals_in[i] : 0u;
             }
         }
+        // all sixteen (atomic, re-read, base) triples are issued before the first result is looked at: the LDS serves a
+        // wave's instructions in order, so step r's re-read sees exactly the counter after step r's atomics (the order of
+        // these instructions in the binary is what the argument rests on: relaxed atomics, checked in the ISA, and
+        // tests/test_gpu_parity.py's list comparisons would show a swap)
+        uint32_t rank[PER_LANE], now[PER_LANE], dstb[PER_LANE];
+#pragma unroll
+        for (int r = 0; r < PER_LANE; r++) {
+            const bool valid = wbeg + r * 64 + lane < wend;
+            const uint32_t d = valid ? (uint32_t)(k[r] >> 32) : 0u;
+            const uint32_t sh = 16 * (d & 1u);
+            rank[r] = 0; now[r] = 1; dstb[r] = 0;
+            if (valid && !(GS2D_DEV_BIN & 4)) {
+                rank[r] = __hip_atomic_fetch_add(&mine[d >> 1], 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                now[r] = __hip_atomic_load(&mine[d >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (valid) dstb[r] = lds[d];
+        }
 #pragma unroll
         for (int r = 0; r < PER_LANE; r++) {
             if (wbeg + r * 64 >= wend) break;  // wave-uniform
             const bool valid = wbeg + r * 64 + lane < wend;
-            const uint32_t d = (uint32_t)(k[r] >> 32);
-            uint64_t peers = __ballot(valid);
-            for (int b = 0; b < nbits; b++) {
-                const uint64_t vote = __ballot((d >> b) & 1u);
-                peers &= ((d >> b) & 1u) ? vote : ~vote;
+            const uint32_t d = valid ? (uint32_t)(k[r] >> 32) : 0u;
+            const uint32_t sh = 16 * (d & 1u);
+            uint32_t rk = rank[r], nw = now[r];
+            if (!(GS2D_DEV_BIN & 4)) { rk = (rk >> sh) & 0xffffu; nw = (nw >> sh) & 0xffffu; }
+            // lanes of this instruction that share a tile: the counter moved by more than one for all of them but the one
+            // served last; re-rank every such tile's lanes in lane order (= element order)
+            uint64_t clash = __ballot(valid && nw != rk + 1u);
+            while (clash) {
+                const int leader = __builtin_ctzll(clash);
+                const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)d, leader);
+                const uint32_t nowl = (uint32_t)__builtin_amdgcn_readlane((int)nw, leader);
+                const uint64_t m = __ballot(valid && d == dl);
+                if (valid && d == dl) rk = nowl - (uint32_t)__popcll(m) + (uint32_t)__popcll(m & lt_mask);
+                clash &= ~m;
             }
-            const uint32_t before = valid ? mine[d] : 0u;
-            __builtin_amdgcn_wave_barrier();
-            if (valid && (peers & lt_mask) == 0) mine[d] = before + (uint32_t)__popcll(peers);
-            __builtin_amdgcn_wave_barrier();
             if (valid) {
-                const uint32_t dst = before + (uint32_t)__popcll(peers & lt_mask);
+                const uint32_t dst = dstb[r] + rk;
                 // one 8-byte store per pair: (depth bits, Gaussian id); the tile id is implied by the position
-                reinterpret_cast<uint2*>(keys_out)[dst] = make_uint2((uint32_t)k[r], v[r]);
+                // (a streaming / non-temporal store here doubles the kernel's time: the L2 is what joins the runs into lines)
+                reinterpret_cast<uint2*>(keys_out)[(GS2D_DEV_BIN & 2) ? (uint32_t)(wbeg + r * 64 + lane) : dst] = make_uint2((uint32_t)k[r], v[r]);
             }
         }
     }
@@ -409,7 +468,7 @@ bin_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restr
 __global__ void __launch_bounds__(BIN_T) bin_scatter_batch_kernel(int ntiles, int nbits, const gs2d::BinFrames tab)
 {
     const gs2d::BinFrame& f = tab.f[blockIdx.y];
-    if ((int)blockIdx.x >= f.nblocks) return;
+    if (f.nblocks == 0) return;
     bin_scatter_body<BIN_ITEMS>(f.keys_unsorted, f.vals_unsorted, f.keys, f.point_list, f.R, ntiles, nbits, f.hist,
                                 f.hist + (size_t)ntiles * f.nblocks, f.nblocks, f.ranges);
 }
@@ -438,7 +497,7 @@ template <int ITEMS>
 __global__ void __launch_bounds__(BIN_T) bin_hist_dev_kernel(const gs2d::DevBin db, int ntiles)
 {
     DevBinPtrs p;
-    if (!dev_bin_ptrs(db, &p, ITEMS) || (int)blockIdx.x >= p.nblocks) return;
+    if (!dev_bin_ptrs(db, &p, ITEMS)) return;
     bin_hist_body<ITEMS>(p.keys_unsorted, p.R, ntiles, p.hist, p.nblocks);
 }
 __global__ void __launch_bounds__(256) bin_row_scan_dev_kernel(const gs2d::DevBin db, int ntiles, int items)
@@ -452,8 +511,7 @@ __global__ void __launch_bounds__(BIN_T) bin_scatter_dev_kernel(const gs2d::DevB
 {
     DevBinPtrs p;
     if (!dev_bin_ptrs(db, &p, ITEMS)) return;
-    // workgroup 0 always runs: it writes the tile ranges (all empty when there are no instances)
-    if ((int)blockIdx.x >= p.nblocks && blockIdx.x != 0) return;
+    // (workgroup 0 always has work: it writes the tile ranges, all empty when there are no instances)
     bin_scatter_body<ITEMS>(p.keys_unsorted, p.vals_unsorted, p.keys, p.point_list, p.R, ntiles, nbits, p.hist,
                      p.hist + (size_t)ntiles * p.nblocks, p.nblocks, ranges);
 }
@@ -502,17 +560,20 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t*
 namespace gs2d {
 
 // Instances per binning workgroup.  Every workgroup clears, writes and reads a whole tile table, so its share of pairs should
-// be a few times the number of tiles -- but the launch should still fill the chip.  count: the number of instances (or the
-// capacity of the chunk when the host does not know it yet); the three kernels of one pass must be given the same value.
+// not be small against the number of tiles -- but small workgroups keep their pairs in registers and fill the chip.  With round
+// 4's bin_scatter (12 B of LDS per tile, ranks from the LDS atomic) the sort stage measures, 4096 / 8192 / 16384 pairs per
+// workgroup: 41 / 38 / 47 us at 1200x680 / 600k, 157 / 165 / 177 us at 876x584 / 2M (77 us of it the stand-alone depth sort),
+// 107 / 105 / 109 us at 1168x876 / 2M (profiles/ab_bin_items_r04.txt).  count: the number of instances (or the capacity of the
+// chunk when the host does not know it yet); the three kernels of one pass must be given the same value.
 int bin_items_for(long long count, int tiles)
 {
     static const int forced = [] { const char* e = getenv("GS2D_BIN_ITEMS_FORCE"); return e ? atoi(e) : 0; }();
     if (forced == 4096 || forced == 8192 || forced == 16384) return forced;
-    if (tiles <= 1536) return BIN_ITEMS;
-    if (count >= 16384LL * 200) return 16384;
-    if (count >= 8192LL * 200) return 8192;
-    return BIN_ITEMS;
+    return tiles > 2560 && count >= 8192LL * 128 ? 8192 : BIN_ITEMS;
 }
+
+static size_t bin_lds_bytes(int tiles) { return 4 * (size_t)(tiles + 2 * (tiles + (tiles & 1))); }  // bin_scatter_body's layout
+static int bin_grid(int nblocks) { return nblocks > 0 ? 8 * ((nblocks + 7) / 8) : 1; }  // see bin_block_of
 
 #define GS2D_BIN_DISPATCH(ITEMS_, ...)                          \
     switch (ITEMS_) {                                          \
@@ -575,9 +636,9 @@ bool launch_bin_by_tile(int R, int tiles, int nbits, const uint64_t* keys_in, co
     const int nblocks = (R + items - 1) / items;
     const size_t hist_elems = (size_t)tiles * nblocks;
     uint32_t* tile_total = hist + hist_elems;  // GS2D_BIN_MAX_TILES words behind the counters (bin_layout)
-    GS2D_BIN_DISPATCH(items, hipLaunchKernelGGL((bin_hist_kernel<I>), dim3(nblocks), dim3(BIN_T), (size_t)tiles * 4, s, keys_in, R, tiles, hist, nblocks));
+    GS2D_BIN_DISPATCH(items, hipLaunchKernelGGL((bin_hist_kernel<I>), dim3(bin_grid(nblocks)), dim3(BIN_T), (size_t)tiles * 4, s, keys_in, R, tiles, hist, nblocks));
     hipLaunchKernelGGL(bin_row_scan_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, hist, tiles, nblocks, tile_total);
-    GS2D_BIN_DISPATCH(items, hipLaunchKernelGGL((bin_scatter_kernel<I>), dim3(nblocks), dim3(BIN_T), (size_t)tiles * 16, s, keys_in, vals_in, keys_out,
+    GS2D_BIN_DISPATCH(items, hipLaunchKernelGGL((bin_scatter_kernel<I>), dim3(bin_grid(nblocks)), dim3(BIN_T), (size_t)bin_lds_bytes(tiles), s, keys_in, vals_in, keys_out,
                                                 vals_out, R, tiles, nbits, hist, tile_total, nblocks, ranges));
     return true;
 }
@@ -587,9 +648,9 @@ void launch_bin_by_tile_dev(const DevBin& db, int tiles, int nbits, uint2* range
     const int items = bin_items_for((long long)db.cap, tiles);
     int grid = ((int)db.cap + items - 1) / items;
     if (grid < 1) grid = 1;
-    GS2D_BIN_DISPATCH(items, hipLaunchKernelGGL((bin_hist_dev_kernel<I>), dim3(grid), dim3(BIN_T), (size_t)tiles * 4, s, db, tiles));
+    GS2D_BIN_DISPATCH(items, hipLaunchKernelGGL((bin_hist_dev_kernel<I>), dim3(bin_grid(grid)), dim3(BIN_T), (size_t)tiles * 4, s, db, tiles));
     hipLaunchKernelGGL(bin_row_scan_dev_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, db, tiles, items);
-    GS2D_BIN_DISPATCH(items, hipLaunchKernelGGL((bin_scatter_dev_kernel<I>), dim3(grid), dim3(BIN_T), (size_t)tiles * 16, s, db, tiles, nbits, ranges));
+    GS2D_BIN_DISPATCH(items, hipLaunchKernelGGL((bin_scatter_dev_kernel<I>), dim3(bin_grid(grid)), dim3(BIN_T), (size_t)bin_lds_bytes(tiles), s, db, tiles, nbits, ranges));
 }
 
 void launch_tile_depth_sort_dev(const DevBin& db, int tiles, const uint2* ranges, int cap_class, int write_keys, hipStream_t s)
@@ -635,9 +696,9 @@ void launch_bin_sort_batch(int P, int K, int tiles, int gx, int nbits, BinFrames
     }
     (void)P; (void)gx;
     if (max_blocks == 0) return;
-    hipLaunchKernelGGL(bin_hist_batch_kernel, dim3(max_blocks, K), dim3(BIN_T), (size_t)tiles * 4, s, tiles, tab);
+    hipLaunchKernelGGL(bin_hist_batch_kernel, dim3(bin_grid(max_blocks), K), dim3(BIN_T), (size_t)tiles * 4, s, tiles, tab);
     hipLaunchKernelGGL(bin_row_scan_batch_kernel, dim3((tiles + 3) / 4, K), dim3(256), 0, s, tiles, tab);
-    hipLaunchKernelGGL(bin_scatter_batch_kernel, dim3(max_blocks, K), dim3(BIN_T), (size_t)tiles * 16, s, tiles, nbits, tab);
+    hipLaunchKernelGGL(bin_scatter_batch_kernel, dim3(bin_grid(max_blocks), K), dim3(BIN_T), (size_t)bin_lds_bytes(tiles), s, tiles, nbits, tab);
     if (!depth_sort) return;  // the forward blend kernel sorts each tile's list itself
     const int cap = tile_sort_capacity(max_R, tiles);  // (launch_tile_depth_sort's rule, on the longest frame)
     hipLaunchKernelGGL(tile_depth_sort_batch_kernel, dim3(tiles, K), dim3(256), (size_t)cap * 16, s, cap, write_keys, tab);

@@ -46,7 +46,7 @@ struct ImgLayout {
 #ifndef GS2D_BIN_ITEMS
 #define GS2D_BIN_ITEMS 4096   // elements per workgroup in the single-pass tile binning
 #endif
-#define GS2D_BIN_MAX_TILES 4096  // 4 waves x tiles x 4 B of LDS counters must fit 64 KB
+#define GS2D_BIN_MAX_TILES 4096  // bin_scatter keeps 12 B of LDS per tile (48 KB here: three workgroups per CU)
 
 static inline GeomLayout geom_layout(int P)
 {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dev tool: per-kernel launch count / mean / total duration from a rocprofv3 --kernel-trace directory, restricted to the
 last `steps` fraction of the run (skips warm-up launches).  usage: kernel_times.py <dir> [tail_fraction=0.3]"""
-import csv, glob, os, sys
+import csv, glob, os, re, sys
 from collections import defaultdict
 d = sys.argv[1]
 frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
@@ -13,7 +13,8 @@ rows.sort()
 rows = rows[int(len(rows) * (1 - frac)):]
 acc = defaultdict(list)
 for s, e, n in rows:
-    k = n.split("(")[0]
+    m = re.search(r"::(\w+)\s*(?:<|\()", n)
+    k = m.group(1) if m else n.split("(")[0]
     for key in ("blend_fwd_kernel", "blend_bwd_kernel"):
         if key in n:
             k = key + ("<batch>" if "ELb1EEEv" in n or "true>" in n.split("(")[0][-8:] else "")

@@ -29,7 +29,7 @@ case "$PART" in
 prof:*)
   for w in $(echo ${PART#prof:} | tr ',' ' '); do prof $w; done ;;
 bench)
-  for w in b200k replica scannetpp scannetpp_ref tracking mapping; do
+  for w in b200k replica scannetpp scannetpp_ref tracking mapping tracking_replica mapping_replica; do
     timeout -k 10 300 python bench.py --workload $w --steps 30 --warmup 5 $B --json-out $OUT/bench_$w.json > $OUT/bench_$w.log 2>&1 || true
     echo "$w: $(python3 -c "import json;d=json.load(open('$OUT/bench_$w.json'));print(d['value'],d['unit'],d['ms_per_step'])" 2>/dev/null)"
   done

@@ -83,3 +83,21 @@ def test_launch_ahead_forward_zero_instances_and_jumps(oracle):
         assert np.abs(h["color"] - o["color"])[:, stable].max() <= 1e-4, name
         assert np.abs(h["allmap"] - o["allmap"])[:, stable].max() <= 1e-4, name
     assert util.oracle_forward(oracle, huge, use_sa=True)["num_rendered"] > 8 * util.oracle_forward(oracle, base, use_sa=True)["num_rendered"]
+
+
+@pytest.mark.parametrize("items", [8192, 16384])
+def test_binning_with_large_workgroups_on_crowded_tiles(items):
+    """bin_scatter ranks a pair among its wave's pairs of the same tile with the LDS atomic's return value and re-ranks the lanes
+    of one instruction that share a tile in lane order (gs2d_binning.hip).  Images of more than 1536 tiles take 8192 / 16384
+    pairs per workgroup (several rounds per wave, the pairs read twice); the scenes of that size in this suite have few pairs
+    per tile, so the re-ranking hardly runs there.  GS2D_BIN_ITEMS_FORCE (read once per process, hence the child process) sends
+    the crowded scenes -- 40 000 splats on six tiles with exact depth ties, where every instruction holds dozens of pairs of
+    one tile -- and the golden vectors through those instantiations; lists, keys and ranges must stay bit-exact."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GS2D_BIN_ITEMS_FORCE=str(items))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_more.py", "-x", "-q", "-m", "gpu", "-k",
+                        "long_tile_lists or golden_vectors or culling_stress"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
