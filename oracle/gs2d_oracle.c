@@ -341,6 +341,14 @@ static inline float relm(float a, float b) /* relative distance of a from thresh
  * distance of any discrete decision (alpha>=1/255, T'>=1e-4, T>0.5,
  * rho3d<=rho2d, depth>=near) from its threshold: pixels with a tiny value
  * are knife-edge and may legitimately flip under 1-ulp arithmetic changes.
+ * Its second plane, stab[HW + pix], receives the CONDITIONING of the depth re-weighting of use_sa (forward.cu:405-416):
+ * exp_std = (D2 - 2 Dp m) / (1 - T) + m^2 is a variance formed by cancellation and conf = exp(-e^2 / (4 exp_std)) divides by
+ * it; where the splats in front of a pixel lie at nearly one depth, exp_std is rounding noise of terms of size m^2 and conf
+ * -- hence the depth channels -- moves by far more than the arithmetic that produced the noise.  The plane holds
+ *   sum_k  w_k |e_k| conf_k (e_k^2 / (4 s_k)) (c_k / s_k),   c_k = m^2 + (|D2| + 2 |Dp m|) / (1 - T),  s_k = exp_std (clamped),
+ * i.e. d(depth) / d(relative perturbation of the cancelling terms): multiplied by the relative rounding of float32 sums
+ * (1e-6, a dozen ulps) it bounds what two correct float32 evaluations of the reference's formulas may differ by at that pixel.
+ * 0 without use_sa.
  */
 void orc_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                    const float* means2D, const float* features, const float* transMats,
@@ -364,7 +372,7 @@ void orc_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_l
                 float Dp = 0, M1 = 0, M2 = 0, D2 = 0, distortion = 0, median_depth = 0;
                 float median_contributor = -1;
                 uint32_t contributor = 0, last_contributor = 0;
-                float margin = 1e30f;
+                float margin = 1e30f, sa_amp = 0.f;
                 uint64_t n_eval = 0, n_pass = 0;
                 for (uint32_t it = r0; it < r1; it++) {
                     contributor++;
@@ -413,6 +421,10 @@ void orc_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_l
                             exp_std = fmax_c(exp_std, 1e-7f);
                             const float e = exp_depth - depth;
                             const float conf = expf(-(e * e) * (1.0f / (4 * exp_std)));
+                            if (stab) {
+                                const float cmag = exp_depth * exp_depth + (fabsf(D2) + 2.0f * fabsf(Dp * exp_depth)) / (1 - T);
+                                sa_amp += w * fabsf(e) * conf * ((e * e) / (4 * exp_std)) * (cmag / exp_std);
+                            }
                             depth = fmaf(conf, depth, (1 - conf) * exp_depth);
                         }
                         Dp = fmaf(depth, w, Dp);
@@ -449,7 +461,7 @@ void orc_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_l
                 const float dstd = fmaf(median_depth * median_depth, 1 - T, fmaf(-2.0f * median_depth, Dp, D2));
                 depth_std_out[pix] = dstd;
                 out_others[pix + 6 * HW] = use_sa ? dstd : distortion;
-                if (stab) stab[pix] = margin;
+                if (stab) { stab[pix] = margin; stab[HW + pix] = sa_amp; }
             }
     }
 }

@@ -128,7 +128,7 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, t
     n_contrib = np.zeros(2 * HW, np.uint32)
     median_depth = np.zeros(HW, np.float32)
     depth_std = np.zeros(HW, np.float32)
-    stab = np.full(HW, 1e30, np.float32) if want_stability else None
+    stab = np.concatenate([np.full(HW, 1e30, np.float32), np.zeros(HW, np.float32)]) if want_stability else None
     features = colors_precomp if colors_precomp is not None else rgb
     tm = transMat_precomp if transMat_precomp is not None else transMats
     if P > 0:
@@ -141,7 +141,8 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, t
               point_offsets=point_offsets, keys_unsorted=keys_unsorted, vals_unsorted=vals_unsorted,
               keys=keys, point_list=point_list, ranges=ranges, nbits=nbits,
               color=out_color, allmap=out_others, final_T=final_T, n_contrib=n_contrib,
-              median_depth=median_depth, depth_std=depth_std, stability=stab)
+              median_depth=median_depth, depth_std=depth_std, stability=None if stab is None else stab[:HW],
+              sa_amp=None if stab is None else stab[HW:])
     return st
 
 
@@ -161,7 +162,7 @@ def reblend(st, ranges, point_list, want_stability=True):
     n_contrib = np.zeros(2 * HW, np.uint32)
     median_depth = np.zeros(HW, np.float32)
     depth_std = np.zeros(HW, np.float32)
-    stab = np.full(HW, 1e30, np.float32) if want_stability else None
+    stab = np.concatenate([np.full(HW, 1e30, np.float32), np.zeros(HW, np.float32)]) if want_stability else None
     features = st["colors_precomp"] if st["colors_precomp"] is not None else st["rgb"]
     tm = st["transMat_precomp"] if st["transMat_precomp"] is not None else st["transMats"]
     if st["P"] > 0:
@@ -171,7 +172,8 @@ def reblend(st, ranges, point_list, want_stability=True):
                         _p(median_depth), _p(depth_std), _p(stab))
     new = dict(st)
     new.update(num_rendered=int(len(point_list)), ranges=ranges, point_list=point_list, color=out_color, allmap=out_others,
-               final_T=final_T, n_contrib=n_contrib, median_depth=median_depth, depth_std=depth_std, stability=stab)
+               final_T=final_T, n_contrib=n_contrib, median_depth=median_depth, depth_std=depth_std,
+               stability=None if stab is None else stab[:HW], sa_amp=None if stab is None else stab[HW:])
     return new
 
 

@@ -40,7 +40,7 @@ def _compare_forward(o, h, W, H, oracle=None):
     np.testing.assert_array_equal(h["last_contributor"][stable], o["n_contrib"][:HW].reshape(H, W)[stable])
     np.testing.assert_array_equal(h["median_contributor"][stable], o["n_contrib"][HW:].reshape(H, W)[stable])
     dc = np.abs(h["color"] - o["color"])[:, stable].max()
-    da = np.abs(h["allmap"] - o["allmap"])[:, stable].max(axis=1)
+    da = util.allmap_dev(h, o, stable)  # (incl. the conditioning allowance of use_sa's depth channels)
     assert dc <= IMG_TOL, dc
     assert (da <= IMG_TOL).all(), da
     if oracle is not None:  # the excluded pixels must equal the oracle under one outcome of their near-threshold decisions

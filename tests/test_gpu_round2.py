@@ -26,7 +26,7 @@ def _fwd_bwd_vs_oracle(oracle, sc, W, H, use_sa=True, channels=(0, 1, 2, 3, 4, 5
     np.testing.assert_array_equal(h["last_contributor"][stable], o["n_contrib"][:HW].reshape(H, W)[stable])
     np.testing.assert_array_equal(h["median_contributor"][stable], o["n_contrib"][HW:].reshape(H, W)[stable])
     assert np.abs(h["color"] - o["color"])[:, stable].max() <= IMG_TOL
-    assert np.abs(h["allmap"] - o["allmap"])[:, stable].max() <= IMG_TOL
+    assert util.allmap_dev(h, o, stable).max() <= IMG_TOL
     if knife_check:
         util.check_knife_pixels(oracle, o, h, stable, IMG_TOL, KNIFE)
     dc, da = util.make_upstream_grads(W, H, channels=channels)

@@ -161,6 +161,38 @@ def rounding_report(gh, go, g64, keys, floor=1e-3):
     return out
 
 
+SA_EPS = 2.0 ** -22  # four float32 ulps: the relative rounding allowed on the cancelling terms of use_sa's depth variance
+
+
+def allmap_dev(h, o, stable, scale=None):
+    """Per channel: the largest deviation of the HIP allmap from the oracle's on the `stable` pixels, after the allowance the
+    CONDITIONING of the reference's own formula grants on the depth channels of use_sa (oracle `sa_amp`, gs2d_oracle.c
+    orc_blend_fwd: forward.cu:405-416 divides by a variance formed by cancellation; where the splats in front of a pixel lie at
+    nearly one depth two correct float32 evaluations differ by sa_amp x their relative rounding).  Allowance: SA_EPS x sa_amp on
+    channel 0 (depth), 8 x that on channel 6 (its error is 2 (d - m) times the depth's); 0 elsewhere and without use_sa.  Found by
+    scripts/dev/fuzz_parity.py (1 pixel of 1088x606 at 2.4e-4, sa_amp 1.0e4; the 99.9th percentile of that image is 22).
+    `h`, `o`: dicts with "allmap" [7,H,W]; o may lack "sa_amp" (fixtures): no allowance then."""
+    d = np.abs(h["allmap"] - o["allmap"]).astype(np.float64)
+    amp = o.get("sa_amp")
+    if amp is not None:
+        a = np.asarray(amp, np.float64).reshape(d.shape[1:]) * SA_EPS
+        d[0] = np.maximum(d[0] - a, 0.0)
+        d[6] = np.maximum(d[6] - 8.0 * a, 0.0)
+    if scale is not None:
+        d = d / np.asarray(scale, np.float64)[:, None, None]
+    return d[:, stable].max(axis=1, initial=0.0)
+
+
+def _sa_allow(o, x, y):
+    """allmap_dev's allowance for one pixel: [7] (non-zero on channels 0 and 6 of an ill-conditioned use_sa pixel)"""
+    out = np.zeros(7)
+    amp = o.get("sa_amp")
+    if amp is not None:
+        a = float(np.asarray(amp).reshape(o["H"], o["W"])[y, x]) * SA_EPS
+        out[0], out[6] = a, 8.0 * a
+    return out
+
+
 def match_knife_variants(orc, o, h, stable, tol, knife, scale=None):
     """For every knife-edge pixel: the outcome of its near-threshold decisions (flip mask of oracle.pixel_variants) under which
     the oracle's pixel equals the HIP pixel (same contributors, smallest error <= tol).  Returns [(x, y, mask)] -- the input of
@@ -175,7 +207,7 @@ def match_knife_variants(orc, o, h, stable, tol, knife, scale=None):
             if v["last_contributor"] != int(h["last_contributor"][y, x]) or v["median_contributor"] != int(h["median_contributor"][y, x]):
                 continue
             e = max(float(np.abs(h["color"][:, y, x] - v["color"]).max()),
-                    float((np.abs(h["allmap"][:, y, x] - v["others"]) / sc).max()))
+                    float((np.maximum(np.abs(h["allmap"][:, y, x] - v["others"]) - _sa_allow(o, x, y), 0.0) / sc).max()))
             if best is None or e < best[0]:
                 best = (e, v["mask"])
         assert best is not None and best[0] <= tol, f"knife-edge pixel ({x},{y}) matches no oracle outcome"
@@ -201,7 +233,7 @@ def check_knife_pixels(orc, o, h, stable, tol, knife, scale=None):
             if v["last_contributor"] != int(h["last_contributor"][y, x]) or v["median_contributor"] != int(h["median_contributor"][y, x]):
                 continue
             e = max(float(np.abs(h["color"][:, y, x] - v["color"]).max()),
-                    float((np.abs(h["allmap"][:, y, x] - v["others"]) / sc).max()))
+                    float((np.maximum(np.abs(h["allmap"][:, y, x] - v["others"]) - _sa_allow(o, x, y), 0.0) / sc).max()))
             best = e if best is None else min(best, e)
         assert best is not None and best <= tol, (
             f"knife-edge pixel ({x},{y}) with {nk} near-threshold decisions matches none of the {len(variants)} oracle outcomes "
