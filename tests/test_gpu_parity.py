@@ -21,7 +21,7 @@ GRAD_TOL = 1e-4
 KNIFE = 2e-5
 
 
-def _compare_forward(o, h, W, H, oracle=None):
+def _compare_forward(o, h, W, H, oracle=None, knife_frac=2e-3):
     assert h["num_rendered"] == o["num_rendered"]
     np.testing.assert_array_equal(h["radii"], o["radii"])
     vis = o["radii"] > 0
@@ -35,7 +35,7 @@ def _compare_forward(o, h, W, H, oracle=None):
     np.testing.assert_array_equal(h["point_list"], o["point_list"])
     np.testing.assert_array_equal(h["ranges"], o["ranges"])
     stable = (o["stability"] > KNIFE).reshape(H, W)
-    assert (~stable).mean() < 2e-3
+    assert (~stable).mean() < knife_frac  # (a sanity bound on the scene, not on the kernels)
     HW = H * W
     np.testing.assert_array_equal(h["last_contributor"][stable], o["n_contrib"][:HW].reshape(H, W)[stable])
     np.testing.assert_array_equal(h["median_contributor"][stable], o["n_contrib"][HW:].reshape(H, W)[stable])
