@@ -5,8 +5,6 @@ render/__init__.py:46-49 (weight-normalised depth, near/far outliers zeroed) fol
 (nan_to_num, depth / silhouette masks, masked L1 sums for tracking, masked means + 0.1*dist-style term for mapping).
 One autograd node, two HIP kernels (csrc/gs2d_loss.hip).  Settings outside the default configuration
 (use_normal_loss, ignore_outliners, enable_exposure) are not covered -- use the PyTorch formulation for those."""
-import ctypes as C
-
 import torch
 
 from . import _lib

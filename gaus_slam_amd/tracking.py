@@ -34,7 +34,6 @@ def matrix_to_quaternion(R: torch.Tensor) -> torch.Tensor:
 def pose_quaternion(pose_Rt: torch.Tensor) -> torch.Tensor:
     """matrix_to_quaternion of the rotation block of a contiguous float32 [3,4] device tensor, computed by one tiny kernel
     (gs2d_pose_quat): no host sync and a single launch instead of ~20 PyTorch ops per tracking iteration."""
-    import ctypes as C
     from . import _lib
     q = torch.empty(4, dtype=torch.float32, device=pose_Rt.device)
     with _r._on_device(pose_Rt.device):
