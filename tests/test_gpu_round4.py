@@ -101,3 +101,78 @@ def test_binning_with_large_workgroups_on_crowded_tiles(items):
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.parametrize("huge", [True, False])
+def test_non_finite_and_degenerate_inputs_do_not_disturb_the_rest(oracle, huge):
+    """NaN, +-Inf, 0, negative and 1e+-30 sprinkled over every input tensor (plus all-zero quaternions and scales): the reference
+    does not trap them ("NaNs are not trapped"; slam/Loss.py:22-25 cleans up afterwards).  Every index
+    the kernels form comes from clamped, saturating conversions (getRect, f2i_sat: CUDA's cvt semantics, NaN -> 0), so nothing may
+    fault or hang, the structural outputs must equal the oracle's bit for bit (num_rendered, radii, tiles_touched, offsets, tile
+    ranges, every tile's SET of Gaussians -- the order among splats whose depth key is a NaN follows the NaN's sign / payload bits,
+    which differ between processors), and the tiles whose lists hold no poisoned Gaussian must come out as if the poison were
+    not there: image within 1e-4 of the oracle's, gradients of the Gaussians that only touch such tiles within 1e-4.
+    huge: with +-Inf / +-1e30 among the poison some splats cover every tile (no clean tile is left: structural checks and the
+    backward's survival only); without them most tiles stay clean."""
+    P, W, H = 12000, 480, 352
+    sc = util.make_scene(P, W, H, seed=9, regime="mapping")
+    rng = np.random.default_rng(1)
+    bad = [float("nan"), float("inf"), -float("inf"), 0.0, -1.0, 1e30, -1e30, 1e-30] if huge else [float("nan"), 0.0, -1.0, 1e-30]
+    poisoned = np.zeros(P, bool)
+    for name, per in (("means3D", 3), ("scales", 2), ("rotations", 4), ("opacities", 1), ("colors", 3)):
+        t = sc[name].clone()
+        idx = rng.choice(t.numel(), 80 if huge else 16, replace=False)
+        for j, i in enumerate(idx):
+            v = bad[j % len(bad)]
+            # (a scale of -1 is a splat a metre wide: it covers every tile; the mild set uses a negative scale of ordinary size)
+            t.view(-1)[int(i)] = -0.004 if (not huge and name == "scales" and v == -1.0) else v
+        poisoned[idx // per] = True
+        sc[name] = t
+    sc["rotations"][10:14] = 0; sc["scales"][20:24] = 0
+    poisoned[10:14] = True; poisoned[20:24] = True
+    oracle.set_threads(os.cpu_count() or 1)
+    o = util.oracle_forward(oracle, sc, use_sa=True)
+    h = util.hip_forward(sc, use_sa=True)  # (reference-binning mode)
+    assert h["num_rendered"] == o["num_rendered"] > 0
+    np.testing.assert_array_equal(h["radii"], o["radii"])
+    np.testing.assert_array_equal(h["tiles_touched"], o["tiles_touched"])
+    np.testing.assert_array_equal(h["point_offsets"], o["point_offsets"])
+    np.testing.assert_array_equal(h["ranges"], o["ranges"])
+    gx = (W + 15) // 16
+    clean_tile = np.ones(o["ranges"].shape[0], bool)
+    for t, (a, b) in enumerate(o["ranges"]):
+        lo, lh = o["point_list"][a:b], h["point_list"][a:b]
+        np.testing.assert_array_equal(np.sort(lo), np.sort(lh))
+        clean_tile[t] = not poisoned[lo].any()
+        if clean_tile[t]:
+            np.testing.assert_array_equal(lo, lh)  # (finite keys: the reference's order)
+    if huge:
+        assert clean_tile.mean() < 0.2
+        dc, da = util.make_upstream_grads(W, H, channels=(0, 1, 2, 3, 4, 5, 6))
+        gh = util.hip_backward(h, (dc * W * H).numpy(), (da * W * H).numpy())  # (a fault or a hang fails the test here)
+        assert gh["dL_dmeans3D"].shape == (P, 3)
+        return
+    assert 0.2 < clean_tile.mean() < 1.0
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    clean_px = clean_tile[(ys // 16) * gx + xs // 16] & (o["stability"] > 2e-5).reshape(H, W)
+    assert np.isfinite(o["color"][:, clean_px]).all() and np.isfinite(o["allmap"][:, clean_px]).all()
+    assert np.abs(h["color"] - o["color"])[:, clean_px].max() <= 1e-4
+    assert util.allmap_dev(h, o, clean_px).max() <= 1e-4
+    # backward: upstream gradients on the clean pixels only (a NaN times a zero gradient is still a NaN: the poisoned tiles
+    # would otherwise flood the atomics of every Gaussian they share with a clean tile)
+    dc, da = util.make_upstream_grads(W, H, channels=(0, 1, 2, 3, 4, 5, 6))
+    dc, da = (dc * W * H).numpy(), (da * W * H).numpy()
+    dc[:, ~clean_px] = 0; da[:, ~clean_px] = 0
+    go = oracle.backward(o, dc, da)
+    gh = util.hip_backward(h, dc, da)  # (a fault or a hang fails the test here)
+    # Gaussians all of whose instances lie in clean tiles
+    only_clean = np.ones(P, bool)
+    for t, (a, b) in enumerate(o["ranges"]):
+        if not clean_tile[t]:
+            only_clean[o["point_list"][a:b]] = False
+    only_clean &= o["radii"] > 0
+    assert only_clean.sum() > 100
+    for k in ["dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dtransMat"]:
+        a, b = gh[k].reshape(P, -1)[only_clean], go[k].reshape(P, -1)[only_clean]
+        assert np.isfinite(b).all() and np.isfinite(a).all(), k
+        assert util.grad_err(a, b) <= 1e-4, k
