@@ -270,7 +270,8 @@ struct FwdFrame {    // one frame: inputs, then the state the phases hand on
     size_t bin_bytes = 0;
     GeomLayout GL; CamParams cam;
     volatile uint32_t* pinned = nullptr;
-    bool fused_sort = false;     // the blend kernel sorts this frame's tile lists itself (phase -1)
+    bool fused_sort = false;     // the blend kernel sorts this frame's tile lists itself (phase -1) ...
+    int sort_cap = 0;            // ... at this capacity (gs2d_fused_sort_cap)
     bool spec = false;           // duplicate runs before the host knows num_rendered (single-pass binning: tiles <= GS2D_BIN_MAX_TILES)
     bool store_pending = false;  // a kernel WILL store into `pinned`: every return path first waits for that store
     bool ahead = false;          // the stages behind duplicate were launched with the count on the device (fwd_phase_b), the host
@@ -477,7 +478,8 @@ int fwd_phase_b(const FwdShared& c, FwdFrame& f, int slot, bool allow_ahead = tr
             // global-memory variant); the sort is fused into the blend kernel at the class its LDS holds anyway
             const long long Rg = same_shape ? (long long)last.R : (long long)C0;
             const int cap_class = gs2d::tile_sort_capacity(Rg, IL.tiles);
-            f.fused_sort = cap_class == GS2D_FUSED_SORT_CAP;
+            f.sort_cap = gs2d::gs2d_fused_sort_cap(cap_class);
+            f.fused_sort = f.sort_cap > 0;
             if (!f.fused_sort) gs2d::launch_tile_depth_sort_dev(db, IL.tiles, ranges, cap_class, 0, s);
             g_timer.end(ST_SORT, s);
             GS2D_STAGE("bin by tile (count on the device)");
@@ -554,8 +556,9 @@ int fwd_phase_b(const FwdShared& c, FwdFrame& f, int slot, bool allow_ahead = tr
         GS2D_STAGE("ranges");
     }
     // The per-tile depth sort: as phase -1 of the blend kernel when the lists fit the LDS its workgroups hold anyway (packed
-    // pairs from the single-pass binning, capacity class 1536), else as the kernel of its own
-    f.fused_sort = one_pass && R > 0 && gs2d::tile_sort_capacity(R, IL.tiles) == GS2D_FUSED_SORT_CAP;
+    // pairs from the single-pass binning, capacity classes up to 3072), else as the kernel of its own
+    f.sort_cap = one_pass && R > 0 ? gs2d::gs2d_fused_sort_cap(gs2d::tile_sort_capacity(R, IL.tiles)) : 0;
+    f.fused_sort = f.sort_cap > 0;
     if (R > 0) {
         if (!f.fused_sort)
             gs2d::launch_tile_depth_sort(R, IL.tiles, ranges, keys, point_list, keys_alt, vals_alt, one_pass ? 1 : 0, debug ? 1 : 0, s);
@@ -699,8 +702,9 @@ int fwd_batch_fused(const FwdShared& c, FwdFrame* f, int K)
     bool any_empty = false;
     for (int k = 0; k < K; k++) { max_R = f[k].R > max_R ? f[k].R : max_R; any_empty = any_empty || f[k].R == 0; }
     // (a frame without instances has no ranges to sort by: keep the stand-alone sort kernel for such a batch)
-    const bool fused_sort = !any_empty && gs2d::tile_sort_capacity(max_R, IL.tiles) == GS2D_FUSED_SORT_CAP;
-    for (int k = 0; k < K; k++) f[k].fused_sort = fused_sort;
+    const int sort_cap = any_empty ? 0 : gs2d::gs2d_fused_sort_cap(gs2d::tile_sort_capacity(max_R, IL.tiles));
+    const bool fused_sort = sort_cap > 0;
+    for (int k = 0; k < K; k++) { f[k].fused_sort = fused_sort; f[k].sort_cap = sort_cap; }
     g_timer.begin(ST_SORT, s);
     gs2d::launch_bin_sort_batch(P, K, IL.tiles, cam0.gx, tile_bits, bin, debug ? 1 : 0, /*depth_sort=*/!fused_sort, s);
     g_timer.end(ST_SORT, s);
@@ -716,9 +720,10 @@ int fwd_phase_c(const FwdShared& c, FwdFrame* frames, int K)
     for (int k = 0; k < K; k++) bf[k] = frames[k].bf;
     g_timer.begin(ST_BLEND_FWD, s);
     bool fused = true;  // (all frames or none: the batch paths decide for the batch as a whole)
-    for (int k = 0; k < K; k++) fused = fused && frames[k].fused_sort;
+    int fused_cap = 0;  // (any capacity sorts any list: longer ones go through global scratch)
+    for (int k = 0; k < K; k++) { fused = fused && frames[k].fused_sort; fused_cap = frames[k].sort_cap > fused_cap ? frames[k].sort_cap : fused_cap; }
     gs2d::launch_blend_fwd(c.width, c.height, K, bf, c.background, c.use_sa, (size_t)c.P * (GS2D_GRAD_FLOATS / 4),
-                           fused ? GS2D_FUSED_SORT_CAP : 0, debug ? 1 : 0, s);
+                           fused ? fused_cap : 0, debug ? 1 : 0, s);
     const bool det = g_deterministic.load() != 0;
     for (int k = 0; k < K; k++) {
         if (frames[k].ahead) continue;  // num_rendered not known yet: fwd_phase_d writes the record

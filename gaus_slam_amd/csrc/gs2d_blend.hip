@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS2D_F
 blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const float* __restrict__ bg, size_t plane, size_t zero_n,
                  int sort_cap, int write_keys, const std::conditional_t<BATCH, gs2d::BlendFwdBatch, gs2d::BlendFwdFrame> args)
 {
-    // ONE dynamic LDS region, used twice: by the depth sort of phase -1 (4 x sort_cap words + 4 x 256 digit counters) and then by
+    // ONE dynamic LDS region, used twice: by the depth sort of phase -1 (4 x sort_cap words, or 2 x sort_cap for the index sort, + 4 x 256 digit counters) and then by
     // the four waves' staging batches (launch_blend_fwd sizes it for the larger of the two)
     extern __shared__ uint32_t dyn_lds[];
     FwdBatch* batches = reinterpret_cast<FwdBatch*>(dyn_lds);
@@ -263,8 +263,12 @@ blend_fwd_kernel(int W, int H, int gx, int ntiles, int blocks_per_frame, const f
     // point_list in global memory (the backward and the cull phase read them); workgroup scope is enough for the waves of
     // this workgroup to see them (see phase 0).
     if (sort_cap > 0) {
-        tile_depth_sort_body(tile, dyn_lds, reinterpret_cast<uint32_t (*)[256]>(dyn_lds + 4 * sort_cap), fa->ranges, sort_keys,
-                             sort_list, sort_keys_alt, sort_vals_alt, sort_cap, /*packed=*/1, write_keys);
+        if (sort_cap > GS2D_FUSED_SORT_CAP)  // (lists of up to 3072 in the same LDS: the index sort, gs2d_tile_sort.h)
+            tile_depth_sort_idx_body(tile, dyn_lds, reinterpret_cast<uint32_t (*)[256]>(dyn_lds + 2 * sort_cap), fa->ranges, sort_keys,
+                                     sort_list, sort_keys_alt, sort_vals_alt, sort_cap, write_keys);
+        else
+            tile_depth_sort_body(tile, dyn_lds, reinterpret_cast<uint32_t (*)[256]>(dyn_lds + 4 * sort_cap), fa->ranges, sort_keys,
+                                 sort_list, sort_keys_alt, sort_vals_alt, sort_cap, /*packed=*/1, write_keys);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1368,7 +1372,7 @@ void launch_blend_fwd(int W, int H, int K, const BlendFwdFrame* frames, const fl
     const size_t plane = (size_t)gx * gy * GS2D_TILE_PIX;
     const int bpf = GS2D_XCDS * ((gx * gy + GS2D_XCDS - 1) / GS2D_XCDS);  // a multiple of 8: blockIdx % 8 picks the same XCD in every frame
     size_t lds = 4 * sizeof(FwdBatch);
-    if (sort_cap > 0 && (size_t)sort_cap * 16 + 4096 > lds) lds = (size_t)sort_cap * 16 + 4096;  // (28 KB at 1536: still 5 workgroups per CU)
+    if (sort_cap > 0 && gs2d_fused_sort_lds(sort_cap) > lds) lds = gs2d_fused_sort_lds(sort_cap);  // (28 KB at 1536 / 3072: still 5 workgroups per CU)
     if (K == 1) {
         if (use_sa)
             hipLaunchKernelGGL((blend_fwd_kernel<true, false>), dim3(bpf), dim3(256), lds, s, W, H, gx, gx * gy, bpf, bg, plane, zero_n,

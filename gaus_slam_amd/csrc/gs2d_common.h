@@ -292,7 +292,15 @@ void launch_duplicate_batch(int P, int K, int gx, const BinFrames& tab, hipStrea
 void launch_bin_sort_batch(int P, int K, int tiles, int gx, int nbits, BinFrames& tab, int write_keys, bool depth_sort, hipStream_t s);
 // LDS capacity (elements) launch_tile_depth_sort picks for R instances on `tiles` tiles: 1536 / 2048 / 3072 / 4096
 int tile_sort_capacity(long long R, int tiles);
-#define GS2D_FUSED_SORT_CAP 1536  // the capacity at which the depth sort fits the LDS a forward blend workgroup holds anyway
+#define GS2D_FUSED_SORT_CAP 1536  // the capacity at which the depth sort (16 B per element) fits the LDS a forward blend workgroup holds anyway
+#define GS2D_FUSED_SORT_CAP_IDX 3072  // ... and at which the index sort (8 B per element, gs2d_tile_sort.h) does
+// capacity the forward blend kernel sorts at itself for a capacity class of tile_sort_capacity (0: the stand-alone kernel)
+static inline int gs2d_fused_sort_cap(int cap_class)
+{
+    return cap_class <= GS2D_FUSED_SORT_CAP ? GS2D_FUSED_SORT_CAP : (cap_class <= GS2D_FUSED_SORT_CAP_IDX ? GS2D_FUSED_SORT_CAP_IDX : 0);
+}
+// dynamic LDS (bytes) of that sort: elements + 4 x 256 digit counters
+static inline size_t gs2d_fused_sort_lds(int sort_cap) { return (size_t)sort_cap * (sort_cap > GS2D_FUSED_SORT_CAP ? 8 : 16) + 4096; }
 
 // Per-frame pointers of the blend kernels.  A launch handles K frames of the same size over the same Gaussians (K = 1: the
 // plain call; K > 1: gs2d_forward_batch / gs2d_backward_batch, one grid over K x tiles).
@@ -321,7 +329,7 @@ struct BlendBwdBatch { BlendBwdFrame f[GS2D_MAX_BATCH]; };
 // Writes hits (u16[4 * i + q] = the 2x2 pixel groups of quadrant q that instance i of the sorted list can touch, see
 // gs2d_cull.h) for every instance, then blends.  Also clears zero_n float4 at `zero` (the backward's gradient accumulator)
 // with its idle store slots.
-// sort_cap > 0 (= GS2D_FUSED_SORT_CAP): every workgroup first sorts its tile's list by depth (the per-tile depth sort as phase
+// sort_cap > 0 (GS2D_FUSED_SORT_CAP: pair sort, GS2D_FUSED_SORT_CAP_IDX: index sort): every workgroup first sorts its tile's list by depth (the per-tile depth sort as phase
 // -1, lists longer than sort_cap through global scratch), write_keys as in launch_tile_depth_sort
 void launch_blend_fwd(int W, int H, int K, const BlendFwdFrame* frames, const float* bg, int use_sa, size_t zero_n, int sort_cap,
                       int write_keys, hipStream_t s);

@@ -88,7 +88,8 @@ def test_scannetpp_reference_config_876x584_2M(oracle):
 def test_lds_sort_capacity_step_3072(oracle):
     """The per-tile depth sort sizes its LDS segment as the smallest of 1536 / 2048 / 3072 / 4096 that is >= 1.3x the mean
     list length (gs2d_binning.hip launch_tile_depth_sort); earlier tests hit 1536, 2048 and the > 4096 global path.  This
-    scene's mean list length selects 3072."""
+    scene's mean list length selects 3072 -- since round 4 sorted inside the forward blend kernel by the INDEX sort (8 bytes of LDS
+    per element, gs2d_tile_sort.h), its longest lists through global scratch."""
     W, H = 160, 128
     P = 66000
     sc = util.make_scene(P, W, H, seed=12, regime="mapping")
