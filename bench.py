@@ -78,7 +78,7 @@ def latest_profile(stem):
 
 
 def main():
-    global PREWARM_STEPS, _ONE_RANK_RCCL
+    global PREWARM_STEPS, PREWARM_SECONDS, _ONE_RANK_RCCL
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="HIP streams a rank spreads its keyframes over (ba_shard.KeyframeShardedBA)")
     ap.add_argument("--prewarm-steps", type=int, default=PREWARM_STEPS, help="upper bound on the untimed steps before the warm-up that take "
                     "the GPU out of its idle clocks (about 1.6 s worth are run; 0 = none); the count is reported in config.prewarm_steps")
+    ap.add_argument("--prewarm-seconds", type=float, default=None, help="target duration of the untimed pre-warm (default %.1f s)" % PREWARM_SECONDS)
     ap.add_argument("--tune-allreduce", action="store_true", help="N > 1: time 1 / 2 / 4 all-reduce chunks overlapped with the "
                     "backward's per-Gaussian stage before the run and use the fastest (default: one whole-bucket all-reduce)")
     ap.add_argument("--rccl-one-rank", action="store_true", help="rehearsal on one GPU: create a ONE-rank RCCL communicator and "
@@ -128,6 +129,8 @@ def main():
         _bs.MIN_COLLECTIVE_WORLD = 1
         os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
     PREWARM_STEPS = max(0, args.prewarm_steps)
+    if args.prewarm_seconds is not None:
+        PREWARM_SECONDS = max(0.0, args.prewarm_seconds)
     # stdout carries exactly ONE line, the JSON: whatever libraries print on file descriptor 1 while the job runs (RCCL writes
     # a five-line version banner there when a communicator is created) goes to stderr instead
     sys.stdout.flush()
