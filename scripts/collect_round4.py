@@ -31,7 +31,7 @@ def put_json(path, name, stamp=None):
     print(name, h)
 
 
-for w in ("op", "b200k", "replica", "scannetpp", "scannetpp_ref", "tracking", "mapping"):
+for w in ("op", "b200k", "replica", "scannetpp", "scannetpp_ref", "tracking", "mapping", "tracking_replica", "mapping_replica"):
     d = os.path.join(src, "prof_" + w)
     if not os.path.isdir(d):
         continue
